@@ -1,0 +1,457 @@
+/*
+ * pdr_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+ *
+ * Plain-C restatement of the native ops on PDR's DDPM reverse-sampling hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product (point_diffusion_refinement_amd) never
+ * does and fails loudly when the HIP library is missing.
+ *
+ * Every function cites the reference source it follows (paths relative to
+ * /root/reference).  Where a reference kernel's result depends on its CUDA
+ * launch geometry (FPS tie order), the geometry is emulated thread by thread.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - the reference's CUDA sources cannot be built here (nvcc/ATen-CUDA
+ *     absent) => no oracle/_ref;
+ *   - EMD is pinned by the reference's own 2-point known answer
+ *     (PytorchEMD/test_emd_loss.py:7-23) and Chamfer by the float64 brute
+ *     force used in pvd/metrics/ChamferDistancePytorch/unit_test.py:22-33;
+ *   - FPS / ball_query / group / gather / three_nn / three_interpolate have
+ *     no reference-side vectors at all: they are pinned against independent
+ *     float64 definitions on tie-free inputs plus constructed tie cases, and
+ *     against the reference *Python* layers run over this oracle
+ *     (tests/golden/make_golden.py);
+ *   - kNN follows pytorch3d (un-vendored, unpinned dependency): PARITY
+ *     UNPINNED at the equal-distance ordering.
+ *
+ * FP contraction model (build with -ffp-contract=off, all fusions explicit):
+ * nvcc's default --fmad=true contracts a*a+b*b+c*c in the LLVM/NVVM order
+ *     t = fadd(fmul a a, fmul b b) -> fma(a,a, b*b);  t + c*c -> fma(c,c,t)
+ * i.e. SUM3(a,b,c) = fmaf(c,c, fmaf(a,a, b*b)).  pytorch3d's accumulate loop
+ * `dist += diff*diff` contracts to ACC3 = fmaf(c,c, fmaf(b,b, a*a)).
+ * Both models live in the two macros below and are mirrored verbatim in
+ * point_diffusion_refinement_amd/csrc/pdr_common.h.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PDR_SUM3(a, b, c) fmaf((c), (c), fmaf((a), (a), (b) * (b)))
+#define PDR_ACC3(a, b, c) fmaf((c), (c), fmaf((b), (b), (a) * (a)))
+
+/* include/cuda_utils.h:13-19 (opt_n_threads): host-side double log */
+int pdr_oracle_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 512) t = 512;
+  if (t < 1) t = 1;
+  return t;
+}
+
+/* ------------------------------------------------------------------ FPS
+ * sampling_gpu.cu:69-173 (kernel), sampling.cpp:66-87 (temp = 1e10, idx = 0).
+ * One CUDA block of `block` threads per cloud; thread tid scans k = tid,
+ * tid+block, ...; tree reduction keeps the LEFT operand on ties (:59-65).
+ */
+int pdr_oracle_furthest_point_sampling(const float *xyz, int B, int N, int m,
+                                       int *idx /* (B,m) */) {
+  if (m <= 0) return 0;
+  const int block = pdr_oracle_opt_n_threads(N);
+  float *temp = (float *)malloc(sizeof(float) * (size_t)N);
+  float *dists = (float *)malloc(sizeof(float) * (size_t)block);
+  int *dists_i = (int *)malloc(sizeof(int) * (size_t)block);
+  if (!temp || !dists || !dists_i) return -1;
+  for (int b = 0; b < B; ++b) {
+    const float *p = xyz + (size_t)b * N * 3;
+    int *out = idx + (size_t)b * m;
+    for (int k = 0; k < N; ++k) temp[k] = 1e10f;
+    for (int j = 0; j < m; ++j) out[j] = 0; /* torch::zeros */
+    int old = 0;
+    out[0] = old;
+    for (int j = 1; j < m; ++j) {
+      const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+      for (int tid = 0; tid < block; ++tid) {
+        int besti = 0;
+        float best = -1.0f;
+        for (int k = tid; k < N; k += block) {
+          const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+          const float mag = PDR_SUM3(x2, y2, z2);
+          if ((double)mag <= 1e-3) continue; /* float vs double literal */
+          const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+          const float d = PDR_SUM3(dx, dy, dz);
+          const float d2 = fminf(d, temp[k]);
+          temp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      for (int s = block / 2; s >= 1; s >>= 1) {
+        for (int tid = 0; tid < s; ++tid) {
+          const float v1 = dists[tid], v2 = dists[tid + s];
+          const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+          dists[tid] = v1 > v2 ? v1 : v2; /* max(v1,v2) */
+          dists_i[tid] = v2 > v1 ? i2 : i1;
+        }
+      }
+      old = dists_i[0];
+      out[j] = old;
+    }
+  }
+  free(temp);
+  free(dists);
+  free(dists_i);
+  return 0;
+}
+
+/* ------------------------------------------------------------ gather
+ * sampling_gpu.cu:8-20: out[b,c,j] = points[b,c,idx[b,j]] */
+int pdr_oracle_gather_points(const float *points, const int *idx, int B, int C,
+                             int N, int m, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < m; ++j)
+        out[((size_t)b * C + c) * m + j] =
+            points[((size_t)b * C + c) * N + idx[(size_t)b * m + j]];
+  return 0;
+}
+
+/* sampling_gpu.cu:34-47: scatter-add (atomicAdd order is unspecified in the
+ * reference; this oracle adds in (c, j) order) */
+int pdr_oracle_gather_points_grad(const float *grad_out, const int *idx, int B,
+                                  int C, int N, int m, float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)B * C * N);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < m; ++j)
+        grad_points[((size_t)b * C + c) * N + idx[(size_t)b * m + j]] +=
+            grad_out[((size_t)b * C + c) * m + j];
+  return 0;
+}
+
+/* -------------------------------------------------------- ball_query
+ * ball_query_gpu.cu:9-47; outputs zero-initialised by ball_query.cpp:21-27 */
+int pdr_oracle_ball_query(const float *new_xyz, const float *xyz, int B, int n,
+                          int m, float radius, int nsample, int *idx,
+                          int *counts) {
+  const float radius2 = radius * radius;
+  memset(idx, 0, sizeof(int) * (size_t)B * m * nsample);
+  memset(counts, 0, sizeof(int) * (size_t)B * m);
+  for (int b = 0; b < B; ++b) {
+    const float *q = new_xyz + (size_t)b * m * 3;
+    const float *p = xyz + (size_t)b * n * 3;
+    int *oi = idx + (size_t)b * m * nsample;
+    int *oc = counts + (size_t)b * m;
+    for (int j = 0; j < m; ++j) {
+      const float nx = q[j * 3 + 0], ny = q[j * 3 + 1], nz = q[j * 3 + 2];
+      for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) {
+        const float dx = nx - p[k * 3 + 0], dy = ny - p[k * 3 + 1],
+                    dz = nz - p[k * 3 + 2];
+        const float d2 = PDR_SUM3(dx, dy, dz);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) oi[j * nsample + l] = k;
+          oi[j * nsample + cnt] = k;
+          ++cnt;
+          oc[j] = cnt;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------- group_points
+ * group_points_gpu.cu:8-28: out[b,c,j,k] = points[b,c,idx[b,j,k]] */
+int pdr_oracle_group_points(const float *points, const int *idx, int B, int C,
+                            int N, int np, int ns, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < np; ++j)
+        for (int k = 0; k < ns; ++k)
+          out[(((size_t)b * C + c) * np + j) * ns + k] =
+              points[((size_t)b * C + c) * N +
+                     idx[((size_t)b * np + j) * ns + k]];
+  return 0;
+}
+
+/* group_points_gpu.cu:43-64 */
+int pdr_oracle_group_points_grad(const float *grad_out, const int *idx, int B,
+                                 int C, int N, int np, int ns,
+                                 float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)B * C * N);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < np; ++j)
+        for (int k = 0; k < ns; ++k)
+          grad_points[((size_t)b * C + c) * N +
+                      idx[((size_t)b * np + j) * ns + k]] +=
+              grad_out[(((size_t)b * C + c) * np + j) * ns + k];
+  return 0;
+}
+
+/* ----------------------------------------------------------- three_nn
+ * interpolate_gpu.cu:9-59: double bests (1e40), float d, strict '<' cascade,
+ * SQUARED distances out. */
+int pdr_oracle_three_nn(const float *unknown, const float *known, int B, int n,
+                        int m, float *dist2, int *idx) {
+  for (int b = 0; b < B; ++b) {
+    const float *u = unknown + (size_t)b * n * 3;
+    const float *kn = known + (size_t)b * m * 3;
+    for (int j = 0; j < n; ++j) {
+      const float ux = u[j * 3 + 0], uy = u[j * 3 + 1], uz = u[j * 3 + 2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        const float dx = ux - kn[k * 3 + 0], dy = uy - kn[k * 3 + 1],
+                    dz = uz - kn[k * 3 + 2];
+        const float d = PDR_SUM3(dx, dy, dz);
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      float *od = dist2 + ((size_t)b * n + j) * 3;
+      int *oi = idx + ((size_t)b * n + j) * 3;
+      od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+      oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
+  }
+  return 0;
+}
+
+/* interpolate_gpu.cu:72-101: p1*w1 + p2*w2 + p3*w3 contracted as
+ * fma(p3,w3, fma(p1,w1, p2*w2)) */
+int pdr_oracle_three_interpolate(const float *points, const int *idx,
+                                 const float *weight, int B, int C, int m,
+                                 int n, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      const float *p = points + ((size_t)b * C + c) * m;
+      for (int j = 0; j < n; ++j) {
+        const float *w = weight + ((size_t)b * n + j) * 3;
+        const int *ii = idx + ((size_t)b * n + j) * 3;
+        out[((size_t)b * C + c) * n + j] =
+            fmaf(p[ii[2]], w[2], fmaf(p[ii[0]], w[0], p[ii[1]] * w[1]));
+      }
+    }
+  return 0;
+}
+
+/* interpolate_gpu.cu:116-143 */
+int pdr_oracle_three_interpolate_grad(const float *grad_out, const int *idx,
+                                      const float *weight, int B, int C, int n,
+                                      int m, float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)B * C * m);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      float *g = grad_points + ((size_t)b * C + c) * m;
+      for (int j = 0; j < n; ++j) {
+        const float *w = weight + ((size_t)b * n + j) * 3;
+        const int *ii = idx + ((size_t)b * n + j) * 3;
+        const float go = grad_out[((size_t)b * C + c) * n + j];
+        g[ii[0]] += go * w[0];
+        g[ii[1]] += go * w[1];
+        g[ii[2]] += go * w[2];
+      }
+    }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- kNN
+ * pytorch3d.ops.knn.knn_points (THIRD PARTY, not vendored, version unpinned by
+ * setup_env.sh:5).  Call sites: pointnet2_utils.py:365,496-497;
+ * chamfer_loss_new.py:149-150.  Published algorithm: brute force, squared L2
+ * accumulated over coordinates (`dist += diff*diff`), K smallest kept, returned
+ * ascending.  Equal distances: lower index first (chosen contract; matches the
+ * in-tree chamfer3D.cu:26-129 "first minimum wins" for K=1).
+ * dists (B,n1,K) f32, idx (B,n1,K) i64.  K <= n2 required (pytorch3d pads with
+ * 0 / -1 otherwise: rows K>n2 get dist 0, idx -1 here as well).
+ */
+int pdr_oracle_knn(const float *x, const float *y, int B, int n1, int n2, int K,
+                   float *dists, int64_t *idx) {
+  float *bd = (float *)malloc(sizeof(float) * (size_t)K);
+  int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)K);
+  if (!bd || !bi) return -1;
+  for (int b = 0; b < B; ++b) {
+    const float *q = x + (size_t)b * n1 * 3;
+    const float *p = y + (size_t)b * n2 * 3;
+    for (int j = 0; j < n1; ++j) {
+      int size = 0;
+      const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+      for (int k = 0; k < n2; ++k) {
+        const float dx = qx - p[k * 3 + 0], dy = qy - p[k * 3 + 1],
+                    dz = qz - p[k * 3 + 2];
+        const float d = PDR_ACC3(dx, dy, dz);
+        /* sorted insertion, stable w.r.t. index (strict '<') */
+        if (size < K) {
+          int pos = size++;
+          while (pos > 0 && d < bd[pos - 1]) {
+            bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos;
+          }
+          bd[pos] = d; bi[pos] = k;
+        } else if (d < bd[K - 1]) {
+          int pos = K - 1;
+          while (pos > 0 && d < bd[pos - 1]) {
+            bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos;
+          }
+          bd[pos] = d; bi[pos] = k;
+        }
+      }
+      for (int t = 0; t < K; ++t) {
+        dists[((size_t)b * n1 + j) * K + t] = t < size ? bd[t] : 0.0f;
+        idx[((size_t)b * n1 + j) * K + t] = t < size ? bi[t] : -1;
+      }
+    }
+  }
+  free(bd);
+  free(bi);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- EMD
+ * PytorchEMD/cuda/emd_kernel.cu:29-161 (approxmatch), host :174-196.
+ * match (B,m,n) indexed [(l)*n + k]; launch <<<32,512>>>: the per-thread
+ * accumulation order over l (pass 1, 3) and k (pass 2) is sequential and is
+ * reproduced here; __expf is restated as expf (GPU parity tolerance 1e-4).
+ */
+int pdr_oracle_approxmatch(const float *xyz1, const float *xyz2, int B, int n,
+                           int m, float *match) {
+  float *remainL = (float *)malloc(sizeof(float) * (size_t)(n + m) * 2);
+  if (!remainL) return -1;
+  float *remainR = remainL + n, *ratioL = remainL + n + m,
+        *ratioR = remainL + n + m + n;
+  float multiL, multiR;
+  if (n >= m) { multiL = 1; multiR = (float)(n / m); }   /* integer division */
+  else        { multiL = (float)(m / n); multiR = 1; }
+  for (int i = 0; i < B; ++i) {
+    const float *p1 = xyz1 + (size_t)i * n * 3;
+    const float *p2 = xyz2 + (size_t)i * m * 3;
+    float *mt = match + (size_t)i * n * m;
+    memset(mt, 0, sizeof(float) * (size_t)n * m);
+    for (int j = 0; j < n; ++j) remainL[j] = multiL;
+    for (int j = 0; j < m; ++j) remainR[j] = multiR;
+    for (int j = 7; j >= -2; --j) {
+      float level = -powf(4.0f, (float)j);
+      if (j == -2) level = 0;
+      for (int k = 0; k < n; ++k) {
+        const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
+        float suml = 1e-9f;
+        for (int l = 0; l < m; ++l) {
+          const float dx = p2[l * 3] - x1, dy = p2[l * 3 + 1] - y1,
+                      dz = p2[l * 3 + 2] - z1;
+          const float d = level * PDR_SUM3(dx, dy, dz);
+          suml += expf(d) * remainR[l];
+        }
+        ratioL[k] = remainL[k] / suml;
+      }
+      for (int l = 0; l < m; ++l) {
+        const float x2 = p2[l * 3], y2 = p2[l * 3 + 1], z2 = p2[l * 3 + 2];
+        float sumr = 0;
+        for (int k = 0; k < n; ++k) {
+          const float dx = x2 - p1[k * 3], dy = y2 - p1[k * 3 + 1],
+                      dz = z2 - p1[k * 3 + 2];
+          sumr += expf(level * PDR_SUM3(dx, dy, dz)) * ratioL[k];
+        }
+        sumr *= remainR[l];
+        const float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);
+        ratioR[l] = consumption * remainR[l];
+        remainR[l] = fmaxf(0.0f, remainR[l] - sumr);
+      }
+      for (int k = 0; k < n; ++k) {
+        const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
+        const float rl = ratioL[k];
+        float suml = 0;
+        for (int l = 0; l < m; ++l) {
+          const float dx = p2[l * 3] - x1, dy = p2[l * 3 + 1] - y1,
+                      dz = p2[l * 3 + 2] - z1;
+          const float w = expf(level * PDR_SUM3(dx, dy, dz)) * rl * ratioR[l];
+          mt[(size_t)l * n + k] += w;
+          suml += w;
+        }
+        remainL[k] = fmaxf(0.0f, remainL[k] - suml);
+      }
+    }
+  }
+  free(remainL);
+  return 0;
+}
+
+/* emd_kernel.cu:204-246 (matchcost): per-thread subsum over (k = tid + 512 q,
+ * all l), then the allsum[512] pairwise tree (:237-242). */
+int pdr_oracle_matchcost(const float *xyz1, const float *xyz2,
+                         const float *match, int B, int n, int m, float *cost) {
+  enum { T = 512 };
+  float allsum[T];
+  for (int i = 0; i < B; ++i) {
+    const float *p1 = xyz1 + (size_t)i * n * 3;
+    const float *p2 = xyz2 + (size_t)i * m * 3;
+    const float *mt = match + (size_t)i * n * m;
+    for (int tid = 0; tid < T; ++tid) {
+      float subsum = 0;
+      for (int k = tid; k < n; k += T) {
+        const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
+        for (int l = 0; l < m; ++l) {
+          const float dx = p2[l * 3] - x1, dy = p2[l * 3 + 1] - y1,
+                      dz = p2[l * 3 + 2] - z1;
+          const float d = PDR_SUM3(dx, dy, dz);
+          subsum = fmaf(d, mt[(size_t)l * n + k], subsum);
+        }
+      }
+      allsum[tid] = subsum;
+    }
+    for (int j = 1; j < T; j <<= 1)
+      for (int tid = 0; tid < T; ++tid)
+        if ((tid & j) == 0 && tid + j < T && (tid & (j - 1)) == 0)
+          allsum[tid] += allsum[tid + j];
+    cost[i] = allsum[0];
+  }
+  return 0;
+}
+
+/* emd_kernel.cu:290-359 (matchcostgrad2 / matchcostgrad1), host :376-401 */
+int pdr_oracle_matchcost_grad(const float *grad_cost, const float *xyz1,
+                              const float *xyz2, const float *match, int B,
+                              int n, int m, float *grad1, float *grad2) {
+  for (int i = 0; i < B; ++i) {
+    const float *p1 = xyz1 + (size_t)i * n * 3;
+    const float *p2 = xyz2 + (size_t)i * m * 3;
+    const float *mt = match + (size_t)i * n * m;
+    const float g = grad_cost[i];
+    for (int l = 0; l < n; ++l) { /* grad1[l] = -sum_k 2 (x2_k - x1_l) match */
+      const float x1 = p1[l * 3], y1 = p1[l * 3 + 1], z1 = p1[l * 3 + 2];
+      float dx = 0, dy = 0, dz = 0;
+      for (int k = 0; k < m; ++k) {
+        const float d = mt[(size_t)k * n + l] * 2;
+        dx += (x1 - p2[k * 3 + 0]) * d;
+        dy += (y1 - p2[k * 3 + 1]) * d;
+        dz += (z1 - p2[k * 3 + 2]) * d;
+      }
+      grad1[((size_t)i * n + l) * 3 + 0] = dx * g;
+      grad1[((size_t)i * n + l) * 3 + 1] = dy * g;
+      grad1[((size_t)i * n + l) * 3 + 2] = dz * g;
+    }
+    for (int k = 0; k < m; ++k) {
+      const float x2 = p2[k * 3], y2 = p2[k * 3 + 1], z2 = p2[k * 3 + 2];
+      float sx = 0, sy = 0, sz = 0;
+      for (int j = 0; j < n; ++j) {
+        const float d = mt[(size_t)k * n + j] * 2;
+        sx += (x2 - p1[j * 3 + 0]) * d;
+        sy += (y2 - p1[j * 3 + 1]) * d;
+        sz += (z2 - p1[j * 3 + 2]) * d;
+      }
+      grad2[((size_t)i * m + k) * 3 + 0] = sx * g;
+      grad2[((size_t)i * m + k) * 3 + 1] = sy * g;
+      grad2[((size_t)i * m + k) * 3 + 2] = sz * g;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,68 @@
+"""ctypes binding of libpdr_hip.so (the C ABI declared in include/pdr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, importing an op raises.  Only device pointers, sizes and the current HIP
+stream cross this boundary -- PyTorch is used for memory and streams, nothing else.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdr_hip.so")
+
+PDR_OK, PDR_EINVAL, PDR_EUNSUPPORTED, PDR_ELAUNCH = 0, -1, -2, -3
+_ERR = {PDR_EINVAL: "invalid argument", PDR_EUNSUPPORTED: "unsupported size", PDR_ELAUNCH: "kernel launch failed"}
+
+_c = ctypes
+_P, _I, _F, _Z = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pdr_hip.h one to one
+SIGNATURES = {
+    "pdr_version": (_I, []),
+    "pdr_last_error": (_c.c_char_p, []),
+    "pdr_opt_n_threads": (_I, [_I]),
+    "pdr_fps_workspace_bytes": (_Z, [_I, _I]),
+    "pdr_furthest_point_sampling": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "pdr_gather_points": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_gather_points_grad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_ball_query": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "pdr_group_points": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "pdr_group_points_grad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "pdr_three_nn": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "pdr_three_interpolate": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_three_interpolate_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_knn_points": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pdr_emd_workspace_bytes": (_Z, [_I, _I, _I]),
+    "pdr_matchcost_workspace_bytes": (_Z, [_I, _I, _I]),
+    "pdr_approxmatch": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "pdr_matchcost": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "pdr_matchcost_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "pdr_emd_cost": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpdr_hip.so; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "point_diffusion_refinement_amd: %s not found. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s/csrc`. "
+                "There is no CPU fallback." % (LIB_PATH, _HERE))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = ABI mismatch, fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != PDR_OK:
+        detail = ""
+        if rc == PDR_ELAUNCH:
+            detail = ": " + (load().pdr_last_error() or b"").decode()
+        raise RuntimeError("%s failed: %s%s" % (what, _ERR.get(rc, "code %d" % rc), detail))

@@ -1,0 +1,78 @@
+// pdr_common.h -- shared device/host helpers for libpdr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pdr_hip.h"
+
+// FP contraction model (see oracle/pdr_oracle.c header; build with
+// -ffp-contract=off so these are the ONLY fusions):
+//   SUM3: nvcc --fmad=true on  a*a + b*b + c*c   (pointnet2_ops, EMD kernels)
+//   ACC3: nvcc --fmad=true on  dist += diff*diff (pytorch3d knn)
+#define PDR_SUM3(a, b, c) __builtin_fmaf((c), (c), __builtin_fmaf((a), (a), (b) * (b)))
+#define PDR_ACC3(a, b, c) __builtin_fmaf((c), (c), __builtin_fmaf((b), (b), (a) * (a)))
+
+#define PDR_WAVE 64
+
+namespace pdr {
+
+void set_last_error(hipError_t e);
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error(e);
+    return PDR_ELAUNCH;
+  }
+  return PDR_OK;
+}
+
+inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- DPP wave reductions (wave64, gfx9 row_shr / row_bcast) -------------------
+// After wave_max_*: lane 63 holds the maximum; callers broadcast with readlane.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  // old = 0, bound_ctrl = false: lanes without a valid source read 0, which is
+  // the identity for max over non-negative keys.
+  return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ unsigned long long u64_from(unsigned hi, unsigned lo) {
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_step_u64(unsigned long long v) {
+  const unsigned lo = dpp_u32<CTRL>(static_cast<unsigned>(v));
+  const unsigned hi = dpp_u32<CTRL>(static_cast<unsigned>(v >> 32));
+  const unsigned long long o = u64_from(hi, lo);
+  return o > v ? o : v;
+}
+
+// returns the wave-wide maximum, uniform across the wave
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = dpp_max_step_u64<0x111>(v);  // row_shr:1
+  v = dpp_max_step_u64<0x112>(v);  // row_shr:2
+  v = dpp_max_step_u64<0x114>(v);  // row_shr:4
+  v = dpp_max_step_u64<0x118>(v);  // row_shr:8  -> lane 15 of each row = row max
+  v = dpp_max_step_u64<0x142>(v);  // row_bcast:15 -> rows 1,3 absorb rows 0,2
+  v = dpp_max_step_u64<0x143>(v);  // row_bcast:31 -> rows 2,3 absorb row 1
+  const unsigned lo = __builtin_amdgcn_readlane(static_cast<unsigned>(v), 63);
+  const unsigned hi = __builtin_amdgcn_readlane(static_cast<unsigned>(v >> 32), 63);
+  return u64_from(hi, lo);
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) {
+  return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+}  // namespace pdr

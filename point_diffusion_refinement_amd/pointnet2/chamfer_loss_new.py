@@ -1,0 +1,134 @@
+"""Chamfer distance / F-score -- same surface as reference pointnet2/chamfer_loss_new.py
+(chamfer_distance :67-217, fscore :219-232, calc_cd :234-245, Chamfer_F1 :247-256).
+
+The two nearest-neighbour searches (pytorch3d knn_points K=1 in the reference,
+:149-150) run on libpdr_hip.so.  Built path = dense clouds of equal length per
+batch (what completion_eval.py feeds); ragged `x_lengths`/`y_lengths` and
+pytorch3d `Pointclouds` inputs are rejected with NotImplementedError.
+All distances are SQUARED; cd_p takes the square root per point before the mean;
+the F-score threshold is applied to squared distances.
+"""
+from typing import Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..pointnet2_ops import _ext
+
+
+def _validate_chamfer_reduction_inputs(batch_reduction: Union[str, None], point_reduction: Union[str, None]):
+    if batch_reduction is not None and batch_reduction not in ["mean", "sum"]:
+        raise ValueError('batch_reduction must be one of ["mean", "sum"] or None')
+    if point_reduction is not None and point_reduction not in ["mean", "sum"]:
+        raise ValueError('point_reduction must be one of ["mean", "sum"]')
+    if point_reduction is None and batch_reduction is not None:
+        raise ValueError('batch_reduction must be set to None if point_reduction is already None')
+
+
+def _dense(points, lengths, normals, name):
+    if not torch.is_tensor(points):
+        raise ValueError("The input pointclouds should be torch.Tensor of shape (minibatch, num_points, 3) "
+                         "(pytorch3d Pointclouds objects are not supported by this build).")
+    if points.ndim != 3:
+        raise ValueError("Expected points to be of shape (N, P, D)")
+    if lengths is not None:
+        if lengths.ndim != 1 or lengths.shape[0] != points.shape[0]:
+            raise ValueError("Expected lengths to be of shape (N,)")
+        if bool((lengths != points.shape[1]).any()):
+            raise NotImplementedError("%s_lengths: ragged clouds are not on the built path" % name)
+    if normals is not None and normals.ndim != 3:
+        raise ValueError("Expected normals to be of shape (N, P, 3")
+    full = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
+    return points, full, normals
+
+
+def _nearest(a, b):
+    d, i, _ = _ext.knn_points(a.contiguous(), b.contiguous(), 1)
+    return d[..., 0], i[..., 0]
+
+
+def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,
+                     batch_reduction: Union[str, None] = "mean", point_reduction: Union[str, None] = "mean"):
+    """Returns (cham_x, cham_y, cham_normals): squared distance from every x point to its
+    nearest y point and vice versa, reduced as requested; (N,P1)/(N,P2) when both reductions are None."""
+    _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
+    x, x_lengths, x_normals = _dense(x, x_lengths, x_normals, "x")
+    y, y_lengths, y_normals = _dense(y, y_lengths, y_normals, "y")
+    with_normals = x_normals is not None and y_normals is not None
+    N, P1, D = x.shape
+    if y.shape[0] != N or y.shape[2] != D:
+        raise ValueError("y does not have the correct shape.")
+    if weights is not None:
+        if weights.size(0) != N:
+            raise ValueError("weights must be of shape (N,).")
+        if not (weights >= 0).all():
+            raise ValueError("weights cannot be negative.")
+        if weights.sum() == 0.0:
+            z = (x.sum((1, 2)) * weights.view(N, 1).squeeze(1))
+            if batch_reduction in ["mean", "sum"]:
+                return z.sum() * 0.0, z.sum() * 0.0
+            return z * 0.0, z * 0.0
+
+    cham_x, idx_x = _nearest(x, y)
+    cham_y, idx_y = _nearest(y, x)
+    norm_x = norm_y = x.new_zeros(())
+    if weights is not None:
+        cham_x = cham_x * weights.view(N, 1)
+        cham_y = cham_y * weights.view(N, 1)
+    if with_normals:
+        near_x = y_normals.gather(1, idx_x.unsqueeze(-1).expand(-1, -1, y_normals.shape[2]))
+        near_y = x_normals.gather(1, idx_y.unsqueeze(-1).expand(-1, -1, x_normals.shape[2]))
+        norm_x = 1 - torch.abs(F.cosine_similarity(x_normals, near_x, dim=2, eps=1e-6))
+        norm_y = 1 - torch.abs(F.cosine_similarity(y_normals, near_y, dim=2, eps=1e-6))
+        if weights is not None:
+            norm_x = norm_x * weights.view(N, 1)
+            norm_y = norm_y * weights.view(N, 1)
+
+    if point_reduction is not None:
+        cham_x, cham_y = cham_x.sum(1), cham_y.sum(1)
+        if with_normals:
+            norm_x, norm_y = norm_x.sum(1), norm_y.sum(1)
+        if point_reduction == "mean":
+            cham_x, cham_y = cham_x / x_lengths, cham_y / y_lengths
+            if with_normals:
+                norm_x, norm_y = norm_x / x_lengths, norm_y / y_lengths
+    if batch_reduction is not None:
+        cham_x, cham_y = cham_x.sum(), cham_y.sum()
+        if with_normals:
+            norm_x, norm_y = norm_x.sum(), norm_y.sum()
+        if batch_reduction == "mean":
+            div = weights.sum() if weights is not None else N
+            cham_x, cham_y = cham_x / div, cham_y / div
+            if with_normals:
+                norm_x, norm_y = norm_x / div, norm_y / div
+    return cham_x, cham_y, (norm_x + norm_y if with_normals else None)
+
+
+def fscore(dist1, dist2, threshold=0.0001):
+    """F-score of two (B,P) SQUARED nearest-neighbour distance maps at `threshold` (also squared)."""
+    p1 = torch.mean((dist1 < threshold).float(), dim=1)
+    p2 = torch.mean((dist2 < threshold).float(), dim=1)
+    f = 2 * p1 * p2 / (p1 + p2)
+    f[torch.isnan(f)] = 0
+    return f, p1, p2
+
+
+def calc_cd(output, gt, calc_f1=False, f1_threshold=0.0001):
+    """cd_p = (mean sqrt d1 + mean sqrt d2)/2, cd_t = mean d1 + mean d2, with d1 = gt->output."""
+    d1, d2, _ = chamfer_distance(gt, output, batch_reduction=None, point_reduction=None)
+    cd_p = (torch.sqrt(d1).mean(1) + torch.sqrt(d2).mean(1)) / 2
+    cd_t = d1.mean(1) + d2.mean(1)
+    if calc_f1:
+        f1, _, _ = fscore(d1, d2, threshold=f1_threshold)
+        return cd_p, cd_t, f1
+    return cd_p, cd_t
+
+
+class Chamfer_F1(nn.Module):
+    def __init__(self, f1_threshold=0.0001):
+        super().__init__()
+        self.f1_threshold = f1_threshold
+
+    def forward(self, xyz1, xyz2):
+        return calc_cd(xyz1, xyz2, calc_f1=True, f1_threshold=self.f1_threshold)

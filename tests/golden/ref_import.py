@@ -1,0 +1,122 @@
+"""Import the reference's Python layers IN THIS CONTAINER ONLY (fixture generation).
+
+/root/reference never travels to the GPU box and is never read by tests, smoke()
+or bench.py at run time.  This helper is used by tests/golden/make_golden.py to run
+the reference's own Python (QueryAndGroup, group_knn, Mlp_plus_t_emb,
+AttentionModule, PointNet2CloudCondition, sampling, VAR/STEP sampling, calc_cd,
+emd.py, point_upsample) on the CPU, with the three native dependencies the image
+lacks replaced by stand-ins backed by the CPU oracle (oracle/pdr_oracle.py):
+
+    pointnet2_ops._ext            -> oracle ops (reference needs nvcc to build it)
+    pytorch3d.ops.knn / structures-> oracle knn   (un-vendored third party)
+    emd_cuda                      -> oracle approxmatch / matchcost
+
+and `.cuda()` patched to identity.  What this pins is everything ABOVE the native
+ops exactly as the reference composes it; the native arithmetic itself is pinned by
+the oracle's own tests.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from oracle import pdr_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _np(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+def make_ext_standin():
+    m = types.ModuleType("pointnet2_ops._ext")
+    m.furthest_point_sampling = lambda pts, n: _t(O.furthest_point_sampling(_np(pts), n))
+    m.gather_points = lambda pts, idx: _t(O.gather_points(_np(pts), _np(idx)))
+    m.gather_points_grad = lambda g, idx, n: _t(O.gather_points_grad(_np(g), _np(idx), n))
+    m.ball_query = lambda new_xyz, xyz, r, ns: tuple(_t(a) for a in O.ball_query(_np(new_xyz), _np(xyz), r, ns))
+    m.group_points = lambda pts, idx: _t(O.group_points(_np(pts), _np(idx)))
+    m.group_points_grad = lambda g, idx, n: _t(O.group_points_grad(_np(g), _np(idx), n))
+    m.three_nn = lambda u, k: [_t(a) for a in O.three_nn(_np(u), _np(k))]
+    m.three_interpolate = lambda p, i, w: _t(O.three_interpolate(_np(p), _np(i), _np(w)))
+    m.three_interpolate_grad = lambda g, i, w, mm: _t(O.three_interpolate_grad(_np(g), _np(i), _np(w), mm))
+    return m
+
+
+class _KNN(tuple):
+    dists = property(lambda s: s[0])
+    idx = property(lambda s: s[1])
+    knn = property(lambda s: s[2])
+
+
+def _knn_points(p1, p2, lengths1=None, lengths2=None, K=1, version=-1, return_nn=False, return_sorted=True):
+    d, i = O.knn(_np(p1), _np(p2), K)
+    d, i = _t(d), _t(i)
+    nn = _knn_gather(p2, i) if return_nn else None
+    return _KNN((d, i, nn))
+
+
+def _knn_gather(x, idx, lengths=None):
+    B, M, C = x.shape
+    _, N, K = idx.shape
+    g = x[:, :, None].expand(-1, -1, K, -1).gather(1, idx.clamp(min=0)[:, :, :, None].expand(-1, -1, -1, C))
+    return g
+
+
+def install():
+    """Pre-seed sys.modules and sys.path; idempotent."""
+    if getattr(install, "_done", False):
+        return
+    sys.dont_write_bytecode = True
+    sys.modules["pointnet2_ops._ext"] = make_ext_standin()
+    p3 = types.ModuleType("pytorch3d")
+    ops = types.ModuleType("pytorch3d.ops")
+    knn = types.ModuleType("pytorch3d.ops.knn")
+    knn.knn_points, knn.knn_gather = _knn_points, _knn_gather
+    ops.knn = knn
+    ops.knn_points, ops.knn_gather = _knn_points, _knn_gather
+    st = types.ModuleType("pytorch3d.structures")
+    pc = types.ModuleType("pytorch3d.structures.pointclouds")
+
+    class Pointclouds:  # only isinstance() is ever applied to it on the dense path
+        pass
+
+    pc.Pointclouds = Pointclouds
+    st.pointclouds = pc
+    p3.ops, p3.structures = ops, st
+    for name, mod in [("pytorch3d", p3), ("pytorch3d.ops", ops), ("pytorch3d.ops.knn", knn),
+                      ("pytorch3d.structures", st), ("pytorch3d.structures.pointclouds", pc)]:
+        sys.modules[name] = mod
+    emd = types.ModuleType("emd_cuda")
+    emd.approxmatch_forward = lambda a, b: _t(O.approxmatch(_np(a), _np(b)))
+    emd.matchcost_forward = lambda a, b, m: _t(O.matchcost(_np(a), _np(b), _np(m)))
+    emd.matchcost_backward = lambda g, a, b, m: [_t(x) for x in O.matchcost_grad(_np(g), _np(a), _np(b), _np(m))]
+    sys.modules["emd_cuda"] = emd
+    # CPU-only container: .cuda() is the identity, tensors report is_cuda for emd.py's assert
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    for p in (REF, os.path.join(REF, "pointnet2"), os.path.join(REF, "pointnet2_ops_lib")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    install._done = True
+
+
+def load_config(name="config_standard_attention_real_3072_partial_points_rot_90_scale_1.2_translation_0.1.json"):
+    import json
+    install()
+    from json_reader import restore_string_to_list_in_a_dict
+    with open(os.path.join(REF, "pointnet2/exp_configs/mvp_configs", name)) as f:
+        cfg = json.load(f)
+    restore_string_to_list_in_a_dict(cfg)
+    return cfg
