@@ -13,11 +13,23 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+_FREQ_CACHE = {}
+
+
+def _frequencies(half, device):
+    # computed on the CPU exactly like the reference (so the f32 values are identical), then kept
+    # resident per device: no per-step H2D copy, and the step stays hipGraph-capturable
+    key = (half, str(device))
+    if key not in _FREQ_CACHE:
+        _FREQ_CACHE[key] = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1))).to(device)
+    return _FREQ_CACHE[key]
+
+
 def calc_t_emb(ts, t_emb_dim):
     """(B,) float steps -> (B, t_emb_dim) [sin(t w_i) | cos(t w_i)], w_i = 10000^(-i/(half-1))."""
     assert t_emb_dim % 2 == 0
     half = t_emb_dim // 2
-    freq = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1))).to(ts.device)
+    freq = _frequencies(half, ts.device)
     arg = ts.unsqueeze(1) * freq
     return torch.cat((torch.sin(arg), torch.cos(arg)), 1)
 

@@ -1,0 +1,166 @@
+"""hipGraph-captured DDPM reverse loop (the MI355X execution model of `util.sampling`).
+
+`util.sampling` (reference util.py:184-255) issues, per reverse step, ~60 native ops,
+~150 1x1-conv GEMMs and several hundred small elementwise kernels from Python, draws
+noise on the CPU and copies it (and the step index) to the GPU.  On MI355X a kernel
+boundary costs ~1.5 us and an eager launch ~3.5 us of host time, so the loop is
+launch-bound long before it is compute-bound.
+
+Here ONE cached-condition reverse step
+        eps = net(x, cond, ts, label);  x <- (x - c1[t] eps) * c2[t] + sigma[t] z
+is captured into a hipGraph once per batch shape and replayed T-1 times:
+  * the step index lives on the device and is decremented inside the graph; the
+    coefficients (1-alpha_t)/sqrt(1-abar_t), 1/sqrt(alpha_t), sigma_t (sigma_0 := 0, the
+    reference adds no noise at t=0) are gathered from device tables;
+  * noise is either drawn on the device inside the graph (Philox, `noise='device'`) or,
+    for seed-parity with the reference, drawn on the CPU default generator and copied
+    into a static buffer before each replay (`noise='cpu'`);
+  * the first step of a batch (condition branch + global PointNet, results retained by
+    the network) runs eagerly, as does graph capture itself.
+The arithmetic per step is the reference's, in the same order.
+"""
+import torch
+
+
+class GraphedReverseSampler:
+    def __init__(self, net, diffusion_hyperparams, noise='device', use_graph=True):
+        assert noise in ('cpu', 'device')
+        self.net = net
+        self.noise = noise
+        self.use_graph = use_graph
+        dh = diffusion_hyperparams
+        self.T = int(dh["T"])
+        self.device = next(net.parameters()).device
+        A, Ab, S = dh["Alpha"].float().cpu(), dh["Alpha_bar"].float().cpu(), dh["Sigma"].float().cpu()
+        # evaluated exactly like `(1-Alpha[t])/torch.sqrt(1-Alpha_bar[t])` and `torch.sqrt(Alpha[t])`
+        self.c_eps = ((1 - A) / torch.sqrt(1 - Ab)).to(self.device)
+        self.sqrt_alpha = torch.sqrt(A).to(self.device)
+        sig = S.clone()
+        sig[0] = 0.0
+        self.sigma = sig.to(self.device)
+        self._graph = None
+        self._key = None
+
+    # ------------------------------------------------------------------ one step
+    def _step(self):
+        t = self._t                                   # () int64 on device
+        ts = t.to(torch.float32).expand(self._x.shape[0])
+        eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
+        x = (self._x - self.c_eps[t] * eps) / self.sqrt_alpha[t]
+        if self.noise == 'device':
+            z = torch.randn_like(x)
+        else:
+            z = self._z
+        self._x.copy_(x + self.sigma[t] * z)
+        self._t.sub_(1)
+
+    def _prepare(self, size, condition, label):
+        key = (tuple(size), tuple(condition.shape), None if label is None else tuple(label.shape))
+        if self._key != key:
+            self._graph = None
+            self._key = key
+            self._x = torch.empty(size, device=self.device)
+            self._z = torch.empty(size, device=self.device)
+            self._cond = torch.empty_like(condition, device=self.device)
+            self._label = None if label is None else torch.empty_like(label, device=self.device)
+            self._t = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._cond.copy_(condition)
+        if label is not None:
+            self._label.copy_(label)
+
+    def _capture(self):
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        saved = (self._x.clone(), self._t.clone())
+        with torch.cuda.stream(s):
+            self._step()                               # warm-up on the side stream (allocator, lazy init)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self._x.copy_(saved[0]), self._t.copy_(saved[1])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step()
+        self._x.copy_(saved[0]), self._t.copy_(saved[1])
+        self._graph = g
+        # the graph has baked in the addresses of the retained condition features
+        self._static_cache = self._cache_tensors()
+
+    _CACHE_ATTRS = ("l_uvw", "encoder_cond_features", "decoder_cond_features")
+
+    def _cache_tensors(self):
+        net = self.net
+        items = [net.global_feature]
+        for name in self._CACHE_ATTRS:
+            items.extend(getattr(net, name) or [])
+        return items
+
+    def _adopt_cache(self):
+        """A new batch produced fresh retained features; move their VALUES into the tensors the captured
+        graph reads and point the network back at those."""
+        net = self.net
+        fresh = self._cache_tensors()
+        assert len(fresh) == len(self._static_cache)
+        for dst, src in zip(self._static_cache, fresh):
+            if dst is not None:
+                dst.copy_(src)
+        it = iter(self._static_cache)
+        net.global_feature = next(it)
+        for name in self._CACHE_ATTRS:
+            cur = getattr(net, name)
+            if cur is not None:
+                setattr(net, name, [next(it) for _ in cur])
+
+    # ------------------------------------------------------------------ public
+    @torch.no_grad()
+    def begin(self, size, condition, label=None, x_T=None, start_step=None):
+        """Load a batch: x_T (drawn like the reference if not given), condition, labels; run the first
+        (uncached) reverse step eagerly so the network retains its condition features."""
+        self._prepare(size, condition, label)
+        self.net.reset_cond_features()
+        if x_T is None:
+            x_T = torch.randn(size, device=self.device) if self.noise == 'device' else torch.normal(0, 1, size=size)
+        self._x.copy_(x_T)
+        t0 = self.T - 1 if start_step is None else int(start_step)
+        self._t.fill_(t0)
+        self.remaining = t0 + 1
+        self._advance_eager()                          # first step: condition branch runs and is retained
+        if self._graph is not None:
+            self._adopt_cache()
+
+    def _draw_cpu_noise(self):
+        # reference order: one draw per step with t > 0, none at t = 0
+        if self.noise == 'cpu' and self.remaining > 1:
+            self._z.copy_(torch.normal(0, 1, size=tuple(self._x.shape)))
+        elif self.noise == 'cpu':
+            self._z.zero_()
+
+    def _advance_eager(self):
+        self._draw_cpu_noise()
+        self._step()
+        self.remaining -= 1
+
+    @torch.no_grad()
+    def advance(self, n=1):
+        """Run n more reverse steps (graph replay)."""
+        for _ in range(n):
+            assert self.remaining > 0, "reverse process already finished"
+            if not self.use_graph:
+                self._advance_eager()
+                continue
+            if self._graph is None:
+                self._capture()
+            self._draw_cpu_noise()
+            self._graph.replay()
+            self.remaining -= 1
+
+    @torch.no_grad()
+    def finish(self):
+        self.advance(self.remaining)
+        out = self._x.clone()
+        self.net.reset_cond_features()
+        return out
+
+    @torch.no_grad()
+    def sample(self, size, condition, label=None, x_T=None):
+        """Equivalent of util.sampling(net, size, dh, label=label, condition=condition)."""
+        self.begin(size, condition, label, x_T)
+        return self.finish()

@@ -1,0 +1,45 @@
+"""Seeded input builders shared by the fixture generator and the tests (CPU generator =>
+identical values in the build container and on the GPU box)."""
+import torch
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def layer_clouds():
+    """xyz (2,96,3) source cloud, new_xyz (2,48,3) queries (first 24 are cloud points, some far away
+    so that subset=False sees empty balls), feats (2,6,96)."""
+    g = _gen(1)
+    xyz = torch.rand(2, 96, 3, generator=g) * 2 - 1
+    new_xyz = torch.rand(2, 48, 3, generator=g) * 2 - 1
+    new_xyz[:, :24] = xyz[:, :24]
+    new_xyz[:, 40:] += 3.0
+    feats = torch.randn(2, 6, 96, generator=g)
+    return xyz.contiguous(), new_xyz.contiguous(), feats.contiguous()
+
+
+def embeddings():
+    g = _gen(2)
+    return torch.randn(2, 64, generator=g), torch.randn(2, 40, generator=g), torch.randn(2, 24, generator=g)
+
+
+def network_inputs(B=2, N=128, M=192):
+    """x_t (B,N,3) ~ N(0,1); condition (B,M,4): xyz in [-1,1]^3, second half mirrored (z -> -z) with flag -1
+    (mirror_partial.py:21-33 shape contract); ts (B,) float; label (B,) long."""
+    g = _gen(3)
+    x = torch.randn(B, N, 3, generator=g)
+    half = torch.rand(B, M // 2, 3, generator=g) * 2 - 1
+    mirrored = half * torch.tensor([1.0, 1.0, -1.0])
+    cond = torch.cat([torch.cat([half, torch.ones(B, M // 2, 1)], 2),
+                      torch.cat([mirrored, -torch.ones(B, M // 2, 1)], 2)], 1)
+    ts = torch.tensor([7.0, 3.0])[:B]
+    label = torch.tensor([3, 11])[:B]
+    return x.contiguous(), cond.contiguous(), ts, label
+
+
+def metric_clouds():
+    g = _gen(4)
+    gt = torch.rand(3, 256, 3, generator=g) - 0.5
+    gen = gt[:, torch.randperm(256, generator=g)] + 0.02 * torch.randn(3, 256, 3, generator=g)
+    return gen.contiguous(), gt.contiguous()

@@ -1,0 +1,195 @@
+"""Generate the committed golden vectors from the REFERENCE's own Python (run in the build
+container only: `python tests/golden/make_golden.py`).
+
+The reference modules are imported from /root/reference through tests/golden/ref_import.py
+(native deps replaced by oracle-backed stand-ins, `.cuda()` patched to identity) and executed
+on the CPU.  Outputs are stored as small .npz files next to this script; inputs are
+regenerated from seeds, weights from tests/golden/det_weights.py.  Nothing here is read at
+test time except the .npz / .txt fixtures.
+"""
+import copy
+import io
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, HERE]
+
+import ref_import as R  # noqa: E402
+
+R.install()
+from det_weights import fill_deterministic  # noqa: E402
+from tiny_config import tiny_pointnet_config  # noqa: E402
+
+import inputs as I  # noqa: E402  (seeded input builders shared with the tests)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024))
+
+
+def quiet(fn, *a, **k):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def layers():
+    from pointnet2_ops import pointnet2_utils as PU
+    from pointnet2_ops.attention import AttentionModule
+    from pointnet2_ops.pointnet2_modules import (FeatureMapModule, Mlp_plus_t_emb, PointnetKnnFPModule,
+                                                 PointnetSAModule, PointnetFPModule)
+    out = {}
+    xyz, new_xyz, feats = I.layer_clouds()
+    for subset in (True, False):
+        for nd in ("radius", "nn"):
+            g = PU.QueryAndGroup(0.35, 8, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=True,
+                                 neighbor_def=nd)
+            o, c = g(xyz, new_xyz, feats, subset=subset, return_counts=True)
+            out["qag_%s_%s" % (nd, subset)] = o
+            if nd == "radius":
+                out["qag_counts_%s" % subset] = c
+    g = PU.QueryAndGroup(0.35, 8, use_xyz=True)
+    out["qag_plain"] = g(xyz, new_xyz[:, :16].contiguous(), None)
+    out["group_knn"] = PU.group_knn(new_xyz, xyz, feats, 4, transpose=True)
+    out["avg_feature"] = PU.average_feature(out["qag_radius_False"], out["qag_counts_False"], 8)
+    with torch.no_grad():
+        t_emb, c_emb, c2_emb = I.embeddings()
+        mlp = fill_deterministic(Mlp_plus_t_emb([15, 32, 32, 48], True, t_dim=64, include_t=True, bias=True,
+                                                res_connect=True, include_condition=True, condition_dim=40,
+                                                include_second_condition=True, second_condition_dim=24), 1)
+        out["mlp"] = mlp(out["qag_radius_False"], t_emb, c_emb, c2_emb)
+        mlp_bn_first = fill_deterministic(Mlp_plus_t_emb([32, 32, 32], True, include_t=False, bn_first=True, bias=True,
+                                                         first_conv=True, first_conv_in_channel=15,
+                                                         res_connect=True), 2)
+        out["mlp_bn_first"] = mlp_bn_first(out["qag_radius_False"])
+        att = fill_deterministic(AttentionModule(6, 15, 6, 15, 48), 3)
+        out["attention"] = att(feats[:, :, :48].contiguous(), out["qag_radius_False"], out["mlp"],
+                               out["qag_counts_False"])
+        out["attention_all"] = att(feats[:, :, :48].contiguous(), out["qag_radius_False"], out["mlp"], 'all')
+        att_set = dict(use_attention_module=True, attention_bn=True, transform_grouped_feat_out=True,
+                       last_activation=True)
+        fm = fill_deterministic(FeatureMapModule([6, 32, 32], 0.35, 8, include_abs_coordinate=True,
+                                                 include_center_coordinate=True, bn_first=False,
+                                                 attention_setting=att_set, query_feature_dim=6), 4)
+        out["feature_map"] = fm(xyz, feats, new_xyz, subset=False, record_neighbor_stats=False,
+                                features_at_new_xyz=feats[:, :, :48].contiguous())
+        sa = fill_deterministic(PointnetSAModule([6, 32, 32, 48], npoint=24, radius=0.4, nsample=8, bias=True,
+                                                 include_abs_coordinate=True, include_center_coordinate=True,
+                                                 t_dim=64, include_t=True, res_connect=True, include_condition=True,
+                                                 condition_dim=40, include_second_condition=True,
+                                                 second_condition_dim=24, attention_setting=att_set), 5)
+        sa_xyz, sa_feat = sa(xyz, feats, t_emb, c_emb, c2_emb)
+        out["sa_xyz"], out["sa_feat"] = sa_xyz, sa_feat
+        sa_pool = fill_deterministic(PointnetSAModule([6, 32, 32, 48], npoint=24, radius=0.4, nsample=8, bias=True), 6)
+        out["sa_pool_feat"] = sa_pool(xyz, feats, pooling='avg_max')[1]
+        fp = fill_deterministic(PointnetKnnFPModule([48, 32, 32], [32 + 6, 32, 32], 4, bias=True, t_dim=64,
+                                                    include_t=True, res_connect=True, include_condition=True,
+                                                    condition_dim=40, include_second_condition=True,
+                                                    second_condition_dim=24, attention_setting=att_set), 7)
+        out["knn_fp"] = fp(xyz, sa_xyz, feats, sa_feat, t_emb, c_emb, c2_emb)
+        fp3 = fill_deterministic(PointnetFPModule([48 + 6, 32, 32], bias=True), 8)
+        out["three_nn_fp"] = fp3(xyz, sa_xyz, feats, sa_feat)
+    save("layers.npz", **out)
+
+
+def network():
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    from models.point_upsample_module import point_upsample
+    from util import calc_diffusion_hyperparams, sampling
+    from util_fastdpmv2 import STEP_sampling, VAR_sampling, get_STEP_step
+    out = {}
+    x, cond, ts, label = I.network_inputs()
+    net = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 11).eval()
+    with torch.no_grad():
+        out["eps_first"] = net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        out["eps_cached"] = net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+        net.reset_cond_features()
+        out["eps_uncached"] = net(x * 0.9, cond, ts=ts - 1, label=label)
+        dh = calc_diffusion_hyperparams(8, 1e-4, 0.02)
+        torch.manual_seed(123)
+        out["sampling_T8"] = quiet(sampling, net, tuple(x.shape), dh, label=label, verbose=False, condition=cond)
+        dh20 = calc_diffusion_hyperparams(20, 1e-4, 0.02)
+        torch.manual_seed(124)
+        out["step_sampling"] = quiet(STEP_sampling, net, tuple(x.shape), dh20,
+                                     get_STEP_step(5, {"T": 20, "beta_0": 1e-4, "beta_T": 0.02}, 'quadratic'), 0.5,
+                                     label=label, verbose=False, condition=cond)
+        eta = np.array([1e-4, 0.004, 0.012, 0.03], dtype=np.float64)
+        torch.manual_seed(125)
+        out["var_sampling"] = quiet(VAR_sampling, net, tuple(x.shape), dh20, eta, 0.5, [17.3, 9.8, 4.1, 0.01],
+                                    label=label, verbose=False, condition=cond)
+        refine = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config(include_t=False,
+                                                                                 point_upsample_factor=4)), 12).eval()
+        disp = refine(x * 0.3, cond, ts=None, label=label)
+        out["refine_displacement"] = disp
+        up, centre = point_upsample(x * 0.3, disp, 4, False, 0.001)
+        out["upsampled"], out["upsample_centre"] = up, centre
+        up2, _ = point_upsample(x * 0.3, disp, 5, True, 0.001)
+        out["upsampled_with_centre"] = up2
+    save("network_tiny.npz", **out)
+
+
+def schedules():
+    from util import calc_diffusion_hyperparams
+    import util_fastdpmv2 as F
+    cfg = {"T": 1000, "beta_0": 1e-4, "beta_T": 0.02}
+    dh = calc_diffusion_hyperparams(**cfg)
+    out = {"Beta": dh["Beta"], "Alpha": dh["Alpha"], "Alpha_bar": dh["Alpha_bar"], "Sigma": dh["Sigma"]}
+    # run the reference's step search with the float64 promotion it was written against (NumPy 1.x);
+    # under NumPy >= 2 the unmodified code stays in float32 and fails its own assert (SURVEY 8c gotcha)
+    orig = F._log_cont_noise
+    F._log_cont_noise = lambda t, b0, bT, T: orig(t, np.float64(b0), np.float64(bT), T)
+    for S in (50, 20):
+        for sch in ("quadratic", "linear"):
+            eta = F.get_VAR_noise(S, cfg, sch)
+            out["eta_%d_%s" % (S, sch)] = eta
+            out["tau_%d_%s" % (S, sch)] = np.array(F._precompute_VAR_steps(dh, eta), dtype=np.float64)
+            out["step_%d_%s" % (S, sch)] = np.array(F.get_STEP_step(S, cfg, sch))
+    F._log_cont_noise = orig
+    save("schedules.npz", **out)
+
+
+def metrics():
+    from chamfer_loss_new import Chamfer_F1, calc_cd, chamfer_distance
+    from emd import EMD_distance, earth_mover_distance
+    out = {}
+    gen, gt = I.metric_clouds()
+    cd_p, cd_t, f1 = Chamfer_F1(f1_threshold=1e-3)(gen, gt)
+    out.update(cd_p=cd_p, cd_t=cd_t, f1=f1)
+    cx, cy, _ = chamfer_distance(gen, gt[:, :200].contiguous())
+    out.update(cham_mean_x=cx, cham_mean_y=cy)
+    cx, cy, _ = chamfer_distance(gen, gt, weights=torch.tensor([0.5, 2.0, 1.0]), batch_reduction="sum",
+                                 point_reduction="sum")
+    out.update(cham_wsum_x=cx, cham_wsum_y=cy)
+    with R.pretend_cuda():
+        out["emd"] = EMD_distance()(gen, gt)
+        cost, match = earth_mover_distance(gen.transpose(1, 2), gt[:, :128].transpose(1, 2), transpose=True,
+                                           return_match=True)
+    out.update(emd_ragged=cost, emd_match_rowsum=match.sum(1), emd_match_colsum=match.sum(2))
+    save("metrics.npz", **out)
+
+
+def state_dict_keys():
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    net = PointNet2CloudCondition(R.load_config()['pointnet_config'])
+    path = os.path.join(HERE, "state_dict_keys_ddpm.txt")
+    with open(path, "w") as f:
+        for k, v in net.state_dict().items():
+            f.write("%s %s\n" % (k, "x".join(str(d) for d in v.shape)))
+    print("wrote state_dict_keys_ddpm.txt (%d tensors, %d parameters)" %
+          (len(net.state_dict()), sum(p.numel() for p in net.parameters())))
+
+
+if __name__ == "__main__":
+    layers()
+    network()
+    schedules()
+    metrics()
+    state_dict_keys()

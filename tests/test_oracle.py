@@ -1,0 +1,227 @@
+"""Pin the CPU oracle (oracle/pdr_oracle.c) BEFORE trusting it as the parity checker.
+
+Reference-side known answers that exist for this path:
+  * EMD 2-point KAT            PytorchEMD/test_emd_loss.py:7-23
+  * Chamfer vs float64 brute   pvd/metrics/ChamferDistancePytorch/unit_test.py:22-33
+Everything else (FPS, ball_query, group, gather, three_nn, kNN) has no reference
+vector; it is pinned against independent float64 / pure-Python definitions, on
+tie-free inputs plus constructed tie cases that exercise the documented tie order.
+"""
+import numpy as np
+import pytest
+
+from oracle import pdr_oracle as O
+
+
+def rng(seed=0):
+    return np.random.default_rng(seed)
+
+
+# ------------------------------------------------------------------ EMD
+def test_emd_two_point_known_answer():
+    p1 = np.array([[[1.7, -0.1, 0.1], [0.1, 1.2, 0.3]]], dtype=np.float32).repeat(3, 0)
+    p2 = np.array([[[0.3, 1.8, 0.2], [1.2, -0.2, 0.3]]], dtype=np.float32).repeat(3, 0)
+    match = O.approxmatch(p1, p2)
+    # optimum pairs p1[0]<->p2[1], p1[1]<->p2[0]; match is (B, m, n) indexed [l, k]
+    np.testing.assert_allclose(match[0], [[0, 1], [1, 0]], atol=1e-6)
+    analytic = ((p1[0, 0] - p2[0, 1]) ** 2).sum() + ((p1[0, 1] - p2[0, 0]) ** 2).sum()   # 0.71
+    np.testing.assert_allclose(O.matchcost(p1, p2, match), analytic, rtol=1e-6)
+    np.testing.assert_allclose(O.emd(p1, p2), analytic / 2, rtol=1e-6)                    # emd.py:16
+    # analytic gradient of the matched pairs (test_emd_loss.py:16-23)
+    g1, g2 = O.matchcost_grad(np.ones(3, np.float32), p1, p2, match)
+    np.testing.assert_allclose(g1[0, 0], 2 * (p1[0, 0] - p2[0, 1]), atol=1e-5)
+    np.testing.assert_allclose(g2[0, 0], 2 * (p2[0, 0] - p1[0, 1]), atol=1e-5)
+
+
+def test_emd_is_a_transport_plan():
+    r = rng(1)
+    a = r.uniform(-0.5, 0.5, (2, 96, 3)).astype(np.float32)
+    b = r.uniform(-0.5, 0.5, (2, 96, 3)).astype(np.float32)
+    match = O.approxmatch(a, b)
+    assert (match >= 0).all()
+    # every point ships (almost) its whole unit mass and receives at most one unit
+    assert np.all(match.sum(1) <= 1 + 1e-4) and np.all(match.sum(2) <= 1 + 1e-4)
+    assert match.sum() > 0.95 * 2 * 96
+    assert np.allclose(O.emd(a, a), 0, atol=1e-5)
+
+
+# -------------------------------------------------------------- Chamfer
+def test_chamfer_vs_float64_bruteforce():
+    r = rng(2)
+    x = r.random((4, 100, 3)).astype(np.float32)
+    y = r.random((4, 200, 3)).astype(np.float32)
+    dx, ix, dy, iy = O.chamfer(x, y)
+    d = ((x[:, :, None, :].astype(np.float64) - y[:, None, :, :].astype(np.float64)) ** 2).sum(-1)
+    assert np.mean((dx - d.min(2)) ** 2) < 1e-8 and np.mean((dy - d.min(1)) ** 2) < 1e-8
+    assert np.array_equal(ix, d.argmin(2)) and np.array_equal(iy, d.argmin(1))
+
+
+# ------------------------------------------------------------------ FPS
+def _fps_greedy_f64(p, m):
+    p = p.astype(np.float64)
+    d = np.full(len(p), 1e10)
+    out = [0]
+    for _ in range(m - 1):
+        d = np.minimum(d, ((p - p[out[-1]]) ** 2).sum(1))
+        out.append(int(d.argmax()))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("n,m", [(64, 16), (200, 50), (512, 128), (1500, 300)])
+def test_fps_is_greedy_maxmin_on_tie_free_input(n, m):
+    x = rng(n).uniform(0.2, 1.0, (3, n, 3)).astype(np.float32)   # away from the |p|^2 <= 1e-3 exclusion
+    idx = O.furthest_point_sampling(x, m)
+    for b in range(3):
+        assert np.array_equal(idx[b], _fps_greedy_f64(x[b], m))
+    assert (idx[:, 0] == 0).all()
+
+
+def _fps_cuda_emulation(p, m):
+    """Pure-Python transcription of the reference kernel's data flow (sampling_gpu.cu:69-173):
+    per-thread strided scan + shared-memory tree, float32 arithmetic via numpy scalars."""
+    n = len(p)
+    block = O.opt_n_threads(n)
+    temp = np.full(n, 1e10, np.float32)
+    f = np.float32
+    out, old = [0], 0
+    for _ in range(1, m):
+        dists, dists_i = np.full(block, -1, np.float32), np.zeros(block, np.int64)
+        for tid in range(block):
+            best, besti = f(-1), 0
+            for k in range(tid, n, block):
+                x2, y2, z2 = p[k]
+                mag = f(x2 * x2) + f(y2 * y2) + f(z2 * z2)
+                if float(mag) <= 1e-3:
+                    continue
+                dd = p[k] - p[old]
+                d = f(f(dd[0] * dd[0]) + f(dd[1] * dd[1])) + f(dd[2] * dd[2])
+                d2 = min(d, temp[k])
+                temp[k] = d2
+                if d2 > best:
+                    best, besti = d2, k
+            dists[tid], dists_i[tid] = best, besti
+        s = block // 2
+        while s >= 1:
+            for tid in range(s):
+                if dists[tid + s] > dists[tid]:
+                    dists[tid], dists_i[tid] = dists[tid + s], dists_i[tid + s]
+            s //= 2
+        old = int(dists_i[0])
+        out.append(old)
+    return np.array(out)
+
+
+def test_fps_tie_order_and_origin_exclusion():
+    # integer lattice => exact float arithmetic (no rounding, FMA-agnostic) and MANY exact ties
+    g = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+    p = g.astype(np.float32)                       # 80 points, includes the origin (excluded: |p|^2 = 0)
+    p = np.concatenate([p, p[5:25]])               # 100 points with duplicates -> block = 64, ragged strides
+    idx = O.furthest_point_sampling(p[None], 40)[0]
+    assert np.array_equal(idx, _fps_cuda_emulation(p, 40))
+    assert 0 not in idx[1:]                        # the origin can never be re-selected
+    # tie rule: bit 0 of the owning reference thread is the MOST significant tie bit
+    q = np.zeros((128, 3), np.float32)
+    q[:] = [1, 0, 0]
+    q[0] = [3, 0, 0]                               # start point
+    # all others equidistant from q[0]: candidates tid=1 (k=1) and tid=32 (k=32) ... winner = lowest bit-reversed tid
+    idx = O.furthest_point_sampling(q[None], 2)[0]
+    assert idx[1] == 64                            # block=128: bitrev7(64)=1 beats bitrev7(1)=64 and bitrev7(2)=32
+    assert np.array_equal(idx, _fps_cuda_emulation(q, 2))
+
+
+def test_fps_all_points_excluded_returns_zeros():
+    p = np.full((1, 32, 3), 0.01, np.float32)      # |p|^2 = 3e-4 <= 1e-3 for every point
+    assert (O.furthest_point_sampling(p, 8) == 0).all()
+
+
+# ----------------------------------------------------------- ball query
+def _ball_query_f64(q, p, r, ns):
+    d = ((q[:, None, :].astype(np.float64) - p[None].astype(np.float64)) ** 2).sum(-1)
+    idx = np.zeros((len(q), ns), np.int32)
+    cnt = np.zeros(len(q), np.int32)
+    for j in range(len(q)):
+        hits = np.nonzero(d[j] < np.float64(np.float32(r) * np.float32(r)))[0][:ns]
+        cnt[j] = len(hits)
+        if len(hits):
+            idx[j] = hits[0]
+            idx[j, :len(hits)] = hits
+    return idx, cnt, d
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(300, 77, 0.25, 8), (1024, 256, 0.2, 32), (16, 16, 1.6, 32), (50, 20, 0.01, 4)])
+def test_ball_query_first_k_in_index_order(n, m, r, ns):
+    rr = rng(n + m)
+    p = rr.uniform(-1, 1, (2, n, 3)).astype(np.float32)
+    q = rr.uniform(-1, 1, (2, m, 3)).astype(np.float32)
+    idx, cnt = O.ball_query(q, p, r, ns)
+    for b in range(2):
+        ei, ec, d = _ball_query_f64(q[b], p[b], r, ns)
+        safe = (np.abs(d - np.float32(r) ** 2) > 1e-5).all(1)     # rows with no borderline pair
+        assert safe.mean() > 0.9
+        assert np.array_equal(idx[b][safe], ei[safe]) and np.array_equal(cnt[b][safe], ec[safe])
+    if r == 0.01:
+        assert (cnt == 0).any() and (idx[cnt == 0] == 0).all()    # empty balls stay all-zero
+
+
+def test_ball_query_strict_inequality_on_exact_distances():
+    p = np.array([[[0, 0, 0], [1, 0, 0], [2, 0, 0], [1, 0, 0]]], np.float32)
+    idx, cnt = O.ball_query(p[:, :1], p, 1.0, 3)                   # d2 == r2 is NOT inside
+    assert cnt[0, 0] == 1 and idx[0, 0].tolist() == [0, 0, 0]
+    idx, cnt = O.ball_query(p[:, :1], p, 1.5, 3)
+    assert cnt[0, 0] == 3 and idx[0, 0].tolist() == [0, 1, 3]
+
+
+# ------------------------------------------------------------ kNN / 3NN
+@pytest.mark.parametrize("n1,n2,K", [(64, 16, 8), (300, 200, 8), (100, 257, 1), (40, 5, 8)])
+def test_knn_sorted_topk(n1, n2, K):
+    rr = rng(n1 * n2)
+    x = rr.uniform(-1, 1, (2, n1, 3)).astype(np.float32)
+    y = rr.uniform(-1, 1, (2, n2, 3)).astype(np.float32)
+    d, i = O.knn(x, y, K)
+    full = ((x[:, :, None].astype(np.float64) - y[:, None].astype(np.float64)) ** 2).sum(-1)
+    k = min(K, n2)
+    order = np.argsort(full, axis=2, kind="stable")[:, :, :k]
+    assert np.array_equal(i[:, :, :k], order)
+    np.testing.assert_allclose(d[:, :, :k], np.take_along_axis(full, order, 2), rtol=1e-5, atol=1e-7)
+    if K > n2:
+        assert (i[:, :, n2:] == -1).all() and (d[:, :, n2:] == 0).all()
+
+
+def test_knn_equal_distances_lower_index_first():
+    y = np.array([[[1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, -1, 0], [2, 0, 0]]], np.float32)
+    d, i = O.knn(np.zeros((1, 1, 3), np.float32), y, 3)
+    assert i[0, 0].tolist() == [0, 1, 2] and d[0, 0].tolist() == [1, 1, 1]
+
+
+def test_three_nn_is_squared_and_cascaded():
+    rr = rng(7)
+    u = rr.uniform(-1, 1, (2, 90, 3)).astype(np.float32)
+    k = rr.uniform(-1, 1, (2, 33, 3)).astype(np.float32)
+    d2, idx = O.three_nn(u, k)
+    full = ((u[:, :, None].astype(np.float64) - k[:, None].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(full, axis=2, kind="stable")[:, :, :3]
+    assert np.array_equal(idx, order)
+    np.testing.assert_allclose(d2, np.take_along_axis(full, order, 2), rtol=1e-5, atol=1e-7)
+    w = rr.random((2, 90, 3)).astype(np.float32)
+    feats = rr.standard_normal((2, 5, 33)).astype(np.float32)
+    out = O.three_interpolate(feats, idx, w)
+    ref = sum(np.take_along_axis(feats, np.broadcast_to(idx[:, None, :, t], (2, 5, 90)), 2) * w[:, None, :, t]
+              for t in range(3))
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------ gather / group
+def test_gather_group_and_their_adjoints():
+    rr = rng(9)
+    feats = rr.standard_normal((2, 7, 50)).astype(np.float32)
+    idx = rr.integers(0, 50, (2, 20)).astype(np.int32)
+    g = O.gather_points(feats, idx)
+    assert np.array_equal(g, np.take_along_axis(feats, np.broadcast_to(idx[:, None], (2, 7, 20)), 2))
+    gidx = rr.integers(0, 50, (2, 11, 6)).astype(np.int32)
+    gg = O.group_points(feats, gidx)
+    assert np.array_equal(gg, np.take_along_axis(feats, np.broadcast_to(gidx.reshape(2, 1, 66), (2, 7, 66)), 2).reshape(2, 7, 11, 6))
+    # <gather(f), w> == <f, gather_grad(w)>  (adjoint identity)
+    w = rr.standard_normal(g.shape).astype(np.float32)
+    np.testing.assert_allclose((g * w).sum(), (feats * O.gather_points_grad(w, idx, 50)).sum(), rtol=1e-4)
+    w = rr.standard_normal(gg.shape).astype(np.float32)
+    np.testing.assert_allclose((gg * w).sum(), (feats * O.group_points_grad(w, gidx, 50)).sum(), rtol=1e-4)

@@ -1,0 +1,279 @@
+"""Parity of the product's Python layers with golden vectors produced by the REFERENCE's own
+Python (tests/golden/make_golden.py, generated in the build container, committed as .npz).
+
+Each check runs twice:
+  * `cpu-oracle`  (no GPU): product layers over the CPU oracle ops  -> must equal the goldens to
+    float32 round-off, because the reference layers ran over the same oracle ops;
+  * `hip` (@gpu): product layers over libpdr_hip.so on cuda:0 -> same neighbourhoods (index-exact
+    ops), values within 1e-4 relative (GEMM/GroupNorm summation order differs on the GPU).
+"""
+import contextlib
+import copy
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import inputs as I
+from tests.golden.det_weights import fill_deterministic
+from tests.golden.tiny_config import tiny_pointnet_config
+from tests.oracle_backend import oracle_ops
+
+from point_diffusion_refinement_amd.pointnet2 import chamfer_loss_new, emd, util, util_fastdpmv2
+from point_diffusion_refinement_amd.pointnet2.models.point_upsample_module import point_upsample
+from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+from point_diffusion_refinement_amd.pointnet2_ops import pointnet2_utils as PU
+from point_diffusion_refinement_amd.pointnet2_ops.attention import AttentionModule
+from point_diffusion_refinement_amd.pointnet2_ops.pointnet2_modules import (FeatureMapModule, Mlp_plus_t_emb,
+                                                                           PointnetFPModule, PointnetKnnFPModule,
+                                                                           PointnetSAModule)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+class Backend:
+    def __init__(self, kind):
+        self.kind = kind
+        self.device = torch.device("cuda:0") if kind == "hip" else torch.device("cpu")
+        # float32 round-off on CPU (same ops, same order) vs 1e-4-class on the GPU
+        self.rtol, self.atol = (1e-5, 1e-6) if kind == "cpu-oracle" else (2e-4, 2e-5)
+
+    def ops(self):
+        return oracle_ops() if self.kind == "cpu-oracle" else contextlib.nullcontext()
+
+    def to(self, *ts):
+        r = tuple(t.to(self.device) if torch.is_tensor(t) else t for t in ts)
+        return r if len(r) > 1 else r[0]
+
+    def close(self, got, want, scale=1.0):
+        got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+        np.testing.assert_allclose(got, want, rtol=self.rtol * scale, atol=self.atol * scale)
+
+
+@pytest.fixture(params=["cpu-oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    if request.param == "hip" and not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    b = Backend(request.param)
+    util.set_device(b.device)
+    util.set_noise_source('cpu')
+    yield b
+    util.set_device(None)
+
+
+ATT = dict(use_attention_module=True, attention_bn=True, transform_grouped_feat_out=True, last_activation=True)
+
+
+def test_grouping_layers(be):
+    g = gold("layers.npz")
+    xyz, new_xyz, feats = be.to(*I.layer_clouds())
+    with be.ops():
+        for subset in (True, False):
+            for nd in ("radius", "nn"):
+                q = PU.QueryAndGroup(0.35, 8, use_xyz=True, include_abs_coordinate=True,
+                                     include_center_coordinate=True, neighbor_def=nd)
+                o, c = q(xyz, new_xyz, feats, subset=subset, return_counts=True)
+                be.close(o, g["qag_%s_%s" % (nd, subset)])
+                if nd == "radius":
+                    assert np.array_equal(c.cpu().numpy(), g["qag_counts_%s" % subset])
+                    assert (g["qag_counts_False"] == 0).any()          # the fixture does contain empty balls
+                else:
+                    assert c == 'all'
+        be.close(PU.QueryAndGroup(0.35, 8)(xyz, new_xyz[:, :16].contiguous(), None), g["qag_plain"])
+        be.close(PU.group_knn(new_xyz, xyz, feats, 4, transpose=True), g["group_knn"])
+        be.close(PU.average_feature(be.to(torch.from_numpy(g["qag_radius_False"])),
+                                    be.to(torch.from_numpy(g["qag_counts_False"])), 8), g["avg_feature"])
+
+
+def test_mlp_attention_and_point_modules(be):
+    g = gold("layers.npz")
+    xyz, new_xyz, feats = be.to(*I.layer_clouds())
+    t_emb, c_emb, c2_emb = be.to(*I.embeddings())
+    grouped = be.to(torch.from_numpy(g["qag_radius_False"]))
+    counts = be.to(torch.from_numpy(g["qag_counts_False"]))
+    q = feats[:, :, :48].contiguous()
+    with torch.no_grad(), be.ops():
+        mlp = fill_deterministic(Mlp_plus_t_emb([15, 32, 32, 48], True, t_dim=64, include_t=True, bias=True,
+                                                res_connect=True, include_condition=True, condition_dim=40,
+                                                include_second_condition=True, second_condition_dim=24), 1)
+        h = mlp.to(be.device)(grouped, t_emb, c_emb, c2_emb)
+        be.close(h, g["mlp"], 5)
+        m2 = fill_deterministic(Mlp_plus_t_emb([32, 32, 32], True, include_t=False, bn_first=True, bias=True,
+                                               first_conv=True, first_conv_in_channel=15, res_connect=True), 2)
+        be.close(m2.to(be.device)(grouped), g["mlp_bn_first"], 5)
+        att = fill_deterministic(AttentionModule(6, 15, 6, 15, 48), 3).to(be.device)
+        hg = be.to(torch.from_numpy(g["mlp"]))
+        be.close(att(q, grouped, hg, counts), g["attention"], 5)
+        be.close(att(q, grouped, hg, 'all'), g["attention_all"], 5)
+        fm = fill_deterministic(FeatureMapModule([6, 32, 32], 0.35, 8, include_abs_coordinate=True,
+                                                 include_center_coordinate=True, bn_first=False,
+                                                 attention_setting=ATT, query_feature_dim=6), 4).to(be.device)
+        be.close(fm(xyz, feats, new_xyz, subset=False, record_neighbor_stats=False, features_at_new_xyz=q),
+                 g["feature_map"], 5)
+        sa = fill_deterministic(PointnetSAModule([6, 32, 32, 48], npoint=24, radius=0.4, nsample=8, bias=True,
+                                                 include_abs_coordinate=True, include_center_coordinate=True,
+                                                 t_dim=64, include_t=True, res_connect=True, include_condition=True,
+                                                 condition_dim=40, include_second_condition=True,
+                                                 second_condition_dim=24, attention_setting=ATT), 5).to(be.device)
+        sa_xyz, sa_feat = sa(xyz, feats, t_emb, c_emb, c2_emb)
+        assert np.array_equal(sa_xyz.cpu().numpy(), g["sa_xyz"])         # FPS picks are exact
+        be.close(sa_feat, g["sa_feat"], 5)
+        sp = fill_deterministic(PointnetSAModule([6, 32, 32, 48], npoint=24, radius=0.4, nsample=8, bias=True),
+                                6).to(be.device)
+        be.close(sp(xyz, feats, pooling='avg_max')[1], g["sa_pool_feat"], 5)
+        sa_feat_g = be.to(torch.from_numpy(g["sa_feat"]))
+        fp = fill_deterministic(PointnetKnnFPModule([48, 32, 32], [32 + 6, 32, 32], 4, bias=True, t_dim=64,
+                                                    include_t=True, res_connect=True, include_condition=True,
+                                                    condition_dim=40, include_second_condition=True,
+                                                    second_condition_dim=24, attention_setting=ATT), 7).to(be.device)
+        be.close(fp(xyz, sa_xyz, feats, sa_feat_g, t_emb, c_emb, c2_emb), g["knn_fp"], 5)
+        fp3 = fill_deterministic(PointnetFPModule([48 + 6, 32, 32], bias=True), 8).to(be.device)
+        be.close(fp3(xyz, sa_xyz, feats, sa_feat_g), g["three_nn_fp"], 5)
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_network_forward_caching_and_samplers(be):
+    g = gold("network_tiny.npz")
+    x, cond, ts, label = be.to(*I.network_inputs())
+    net = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 11).eval().to(be.device)
+    with torch.no_grad(), be.ops():
+        be.close(net(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"], 10)
+        assert net.l_uvw is not None and net.global_feature is not None
+        be.close(net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True), g["eps_cached"], 10)
+        net.reset_cond_features()
+        assert net.l_uvw is None and net.encoder_cond_features is None and net.decoder_cond_features is None
+        be.close(net(x * 0.9, cond, ts=ts - 1, label=label), g["eps_uncached"], 10)
+        assert net.l_uvw is None                                          # no retention without the flag
+
+        # identical seeds == identical CPU noise stream (x_T, z_{T-1} .. z_1)
+        dh = util.calc_diffusion_hyperparams(8, 1e-4, 0.02)
+        torch.manual_seed(123)
+        out = _quiet(util.sampling, net, tuple(x.shape), dh, label=label, verbose=False, condition=cond)
+        be.close(out, g["sampling_T8"], 50)
+        assert net.l_uvw is None                                          # sampling() resets the cache
+        dh20 = util.calc_diffusion_hyperparams(20, 1e-4, 0.02)
+        steps = util_fastdpmv2.get_STEP_step(5, {"T": 20, "beta_0": 1e-4, "beta_T": 0.02}, 'quadratic')
+        torch.manual_seed(124)
+        out = _quiet(util_fastdpmv2.STEP_sampling, net, tuple(x.shape), dh20, steps, 0.5, label=label,
+                     verbose=False, condition=cond)
+        be.close(out, g["step_sampling"], 50)
+        eta = np.array([1e-4, 0.004, 0.012, 0.03], dtype=np.float64)
+        torch.manual_seed(125)
+        out = _quiet(util_fastdpmv2.VAR_sampling, net, tuple(x.shape), dh20, eta, 0.5, [17.3, 9.8, 4.1, 0.01],
+                     label=label, verbose=False, condition=cond)
+        be.close(out, g["var_sampling"], 50)
+
+
+def test_refinement_network_and_upsampling(be):
+    g = gold("network_tiny.npz")
+    x, cond, ts, label = be.to(*I.network_inputs())
+    cfg = tiny_pointnet_config(include_t=False, point_upsample_factor=4)
+    net = fill_deterministic(PointNet2CloudCondition(cfg), 12).eval().to(be.device)
+    assert cfg["out_dim"] == 15                                           # 3 * (f + 1)
+    with torch.no_grad(), be.ops():
+        disp = net(x * 0.3, cond, ts=None, label=label)
+    be.close(disp, g["refine_displacement"], 10)
+    dg = be.to(torch.from_numpy(g["refine_displacement"]))
+    up, centre = point_upsample(x * 0.3, dg, 4, False, 0.001)
+    be.close(up, g["upsampled"])
+    be.close(centre, g["upsample_centre"])
+    assert up.shape == (2, 128 * 4, 3)
+    be.close(point_upsample(x * 0.3, dg, 5, True, 0.001)[0], g["upsampled_with_centre"])
+
+
+def test_metrics_python_surface(be):
+    g = gold("metrics.npz")
+    gen, gt = be.to(*I.metric_clouds())
+    with be.ops():
+        cd_p, cd_t, f1 = chamfer_loss_new.Chamfer_F1(f1_threshold=1e-3)(gen, gt)
+        be.close(cd_p, g["cd_p"]), be.close(cd_t, g["cd_t"]), be.close(f1, g["f1"])
+        cx, cy, _ = chamfer_loss_new.chamfer_distance(gen, gt[:, :200].contiguous())
+        be.close(cx, g["cham_mean_x"]), be.close(cy, g["cham_mean_y"])
+        w = be.to(torch.tensor([0.5, 2.0, 1.0]))
+        cx, cy, _ = chamfer_loss_new.chamfer_distance(gen, gt, weights=w, batch_reduction="sum", point_reduction="sum")
+        be.close(cx, g["cham_wsum_x"]), be.close(cy, g["cham_wsum_y"])
+        if be.kind == "cpu-oracle":
+            emd_dist = emd.EMD_distance.forward
+            # emd.py asserts CUDA tensors exactly like the reference; exercise the arithmetic below the assert
+            cost = emd.emd_cost_fused(gen.contiguous(), gt.contiguous()) / 256
+            be.close(cost, g["emd"], 10)
+        else:
+            be.close(emd.EMD_distance()(gen, gt), g["emd"], 1)
+            cost, match = emd.earth_mover_distance(gen.transpose(1, 2), gt[:, :128].transpose(1, 2), transpose=True,
+                                                   return_match=True)
+            be.close(cost, g["emd_ragged"], 1)
+            np.testing.assert_allclose(match.sum(1).cpu().numpy(), g["emd_match_rowsum"], rtol=1e-3, atol=1e-4)
+            np.testing.assert_allclose(match.sum(2).cpu().numpy(), g["emd_match_colsum"], rtol=1e-3, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        with be.ops():
+            chamfer_loss_new.chamfer_distance(gen, gt, x_lengths=be.to(torch.tensor([256, 100, 256])))
+    with pytest.raises(ValueError):
+        chamfer_loss_new.chamfer_distance(gen, gt, batch_reduction="max")
+
+
+# ----------------------------------------------------------------- host-only goldens
+def test_diffusion_hyperparameters_and_fastdpm_schedules():
+    g = gold("schedules.npz")
+    cfg = {"T": 1000, "beta_0": 1e-4, "beta_T": 0.02}
+    dh = util.calc_diffusion_hyperparams(**cfg)
+    for k in ("Beta", "Alpha", "Alpha_bar", "Sigma"):
+        assert np.array_equal(dh[k].numpy(), g[k])                        # sequential f32 products, bit-exact
+    # spot values quoted in SURVEY 8c(5)
+    assert abs(float(dh["Alpha_bar"][999]) - 4.0358e-5) < 1e-8
+    assert abs(float(dh["Sigma"][999]) - 0.141421) < 1e-5 and abs(float(dh["Sigma"][0]) - 0.01) < 1e-6
+    for S in (50, 20):
+        for sch in ("quadratic", "linear"):
+            eta = util_fastdpmv2.get_VAR_noise(S, cfg, sch)
+            np.testing.assert_array_equal(eta, g["eta_%d_%s" % (S, sch)])
+            tau = np.array(util_fastdpmv2._precompute_VAR_steps(dh, eta))
+            np.testing.assert_allclose(tau, g["tau_%d_%s" % (S, sch)], atol=1e-4)
+            assert abs(tau[-1]) < 0.1 and np.all(np.diff(tau) < 0)        # the reference's own assert
+            assert util_fastdpmv2.get_STEP_step(S, cfg, sch) == g["step_%d_%s" % (S, sch)].tolist()
+    tau = g["tau_50_quadratic"]
+    np.testing.assert_allclose(tau[[0, 1, 2, -3, -2, -1]], [998.995, 964.836, 931.433, 9.836, 3.909, 0.00015],
+                               atol=2e-3)                                  # SURVEY 8c gotcha row
+
+
+def test_state_dict_is_key_for_key_compatible_with_the_ddpm_config():
+    """837 tensors / 9,758,871 parameters, names such as SA_modules.0.mlps.0.first_mlp.0.weight."""
+    cfg = {
+        "in_fea_dim": 0, "partial_in_fea_dim": 1, "out_dim": 3, "include_t": True, "t_dim": 128,
+        "model.use_xyz": True, "attach_position_to_input_feature": True, "include_abs_coordinate": True,
+        "include_center_coordinate": True, "record_neighbor_stats": False, "bn_first": False, "bias": True,
+        "res_connect": True, "include_class_condition": True, "num_class": 16, "class_condition_dim": 128,
+        "bn": True, "include_local_feature": True, "include_global_feature": True,
+        "global_feature_remove_last_activation": False,
+        "pnet_global_feature_architecture": [[4, 128, 256], [512, 1024]],
+        "attention_setting": dict(ATT, add_attention_to_FeatureMapper_module=True),
+        "architecture": {"npoint": [1024, 256, 64, 16], "radius": [0.1, 0.2, 0.4, 0.8],
+                         "neighbor_definition": "radius", "nsample": [32, 32, 32, 32],
+                         "feature_dim": [32, 64, 128, 256, 512], "mlp_depth": 3,
+                         "decoder_feature_dim": [128, 128, 256, 256, 512], "include_grouper": False,
+                         "decoder_mlp_depth": 2, "use_knn_FP": True, "K": 8},
+        "condition_net_architecture": {"npoint": [1024, 256, 64, 16], "radius": [0.1, 0.2, 0.4, 0.8],
+                                       "neighbor_definition": "radius", "nsample": [32, 32, 32, 32],
+                                       "feature_dim": [32, 32, 64, 64, 128], "mlp_depth": 3,
+                                       "decoder_feature_dim": [32, 32, 64, 64, 128], "include_grouper": False,
+                                       "decoder_mlp_depth": 2, "use_knn_FP": True, "K": 8},
+        "feature_mapper_architecture": {"neighbor_definition": "radius",
+                                        "encoder_feature_map_dim": [32, 32, 64, 64], "encoder_mlp_depth": 2,
+                                        "encoder_radius": [0.1, 0.2, 0.4, 0.8], "encoder_nsample": [32, 32, 32, 32],
+                                        "decoder_feature_map_dim": [32, 32, 64, 64, 128], "decoder_mlp_depth": 2,
+                                        "decoder_radius": [0.1, 0.2, 0.4, 0.8, 1.6],
+                                        "decoder_nsample": [32, 32, 32, 32, 32]},
+    }
+    net = PointNet2CloudCondition(copy.deepcopy(cfg))
+    want = [l.split() for l in open(os.path.join(GOLD, "state_dict_keys_ddpm.txt")).read().splitlines()]
+    got = [[k, "x".join(str(d) for d in v.shape)] for k, v in net.state_dict().items()]
+    assert got == want and len(got) == 837
+    assert sum(p.numel() for p in net.parameters()) == 9758871
