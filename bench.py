@@ -40,12 +40,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="clouds per GPU (BASELINE: 32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--unfused", action="store_true",
+                    help="layer-by-layer PyTorch execution over the native ops instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
 
-def build_sampler(device, use_graph):
+def build_sampler(device, use_graph, fused=True):
     from point_diffusion_refinement_amd.pointnet2 import util
     from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG, ddpm_pointnet_config
     from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import \
@@ -54,7 +56,11 @@ def build_sampler(device, use_graph):
     torch.manual_seed(0)
     net = PointNet2CloudCondition(ddpm_pointnet_config()).to(device).eval()
     dh = util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG)
-    return GraphedReverseSampler(net, dh, noise='device', use_graph=use_graph), net
+    model = net
+    if fused:
+        from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
+        model = FusedCloudConditionNet(net)
+    return GraphedReverseSampler(model, dh, noise='device', use_graph=use_graph), net
 
 
 def cpu_baseline(budget_s):
@@ -105,7 +111,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from point_diffusion_refinement_amd.pointnet2.configs import synthetic_batch
-    sampler, net = build_sampler(device, not args.no_graph)
+    sampler, net = build_sampler(device, not args.no_graph, fused=not args.unfused)
     B = args.batch
     # every rank draws ITS OWN shard of the synthetic partial clouds (seed offset by rank)
     x_T, cond, label = synthetic_batch(B, N_POINTS, M_COND, seed=rank, device=device)
@@ -142,7 +148,8 @@ def main():
                                "reverse sampling, random-init dual-path PointNet++ (9.76 M params), cached "
                                "condition step" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world,
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "noise": "device Philox"},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "noise": "device Philox",
+                   "execution": "layer-by-layer torch + native ops" if args.unfused else "fused channel-last HIP"},
         "completed_points_per_s_per_gpu": round(value / world * N_POINTS / T_STEPS, 2),
         "first_uncached_step_ms": round(first_step_s * 1e3, 2),
         "gemm_tflops": round(value * GEMM_GFLOP_PER_CLOUD_STEP / 1e3, 2),

@@ -140,6 +140,80 @@ int pdr_matchcost_grad(const float *grad_cost, const float *xyz1,
 int pdr_emd_cost(const float *xyz1, const float *xyz2, int B, int n, int m,
                  float *cost, float *temp, pdr_stream_t stream);
 
+/* ==== fused channel-LAST layer kernels ========================================
+ * These have no single pybind counterpart: each replaces a COMPOSITION of torch ops
+ * the reference issues from Python on (B,C,npoint,K) tensors.  Activations here are
+ * channel-last: X is (P positions, C channels), P = B*npoint*K.
+ *
+ * pdr_fused_layer   = [GroupNorm apply -> ReLU -> + embedding rows -> + residual ->
+ *                      torch.cat of inputs] -> Conv2d 1x1 (+bias) -> moments of the output
+ *                     (pointnet2_modules.py:42-67 build_shared_mlp, :69-174 Mlp_plus_t_emb,
+ *                      attention.py:43-55 weight_conv / :60-66 feat_out_conv)
+ * pdr_gn_reduce / pdr_gn_finalize = nn.GroupNorm statistics (MyGroupNorm,
+ *                      pointnet2_modules.py:23-40) folded to per-(batch,channel) y = x*scale+shift
+ * pdr_group_build   = QueryAndGroup.forward after ball_query (pointnet2_utils.py:368-414)
+ * pdr_knn_build     = group_knn after knn_points (pointnet2_utils.py:497-510)
+ * pdr_attention_pool= mask, softmax over K, weighted sum (attention.py:83-96)
+ * pdr_gather_rows   = gather_operation on a channel-last matrix
+ */
+typedef struct {
+  const float *ptr; /* (rows, C) with leading dimension ld */
+  int C;
+  int ld;
+  int row_div;      /* source row = position / row_div (broadcast over K neighbours) */
+} pdr_seg_t;
+
+typedef struct {
+  int n_seg;            /* 1..4 channel segments, concatenated in order */
+  pdr_seg_t seg[4];
+  const float *scale;   /* (B,Cin) or NULL(=1)  x' = post(pre(x)*scale + shift) + add + radd */
+  const float *shift;   /* (B,Cin) or NULL(=0) */
+  const float *add;     /* (B,Cin) rows of leading dimension add_ld, or NULL */
+  const float *radd;    /* (P,>=Cin) row-wise residual or NULL */
+  int add_ld;
+  int radd_ld;
+  int pre_relu, post_relu;
+  int rows_per_batch;   /* npoint*K; must be a multiple of 32 */
+} pdr_layer_in_t;
+
+/* rows per workgroup tile chosen for `rows_per_batch` (128/64/32; 0 = unsupported) */
+int pdr_fused_layer_tile_rows(int rows_per_batch);
+/* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight
+ * transposed), exact fp32 MFMA.  partial: NULL or (P/tile_rows, Cout, 2) floats receiving the
+ * per-tile sum / sum of squares of y (columns >= relu_col0: of relu(y)). */
+int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt,
+                    const float *bias, int Cout, float *Y, int ldy, float *partial,
+                    int relu_col0, pdr_stream_t stream);
+/* chan_stats[b, coff+c] (double sum, double sumsq) = mult * sum over tiles of batch b;
+ * `partial` points at the first of C columns inside rows of ldp columns */
+int pdr_gn_reduce(const float *partial, int ldp, int B, int tiles_per_batch, int C, double mult,
+                  double *chan_stats, int Ctot, int coff, pdr_stream_t stream);
+/* out (P,C; ld ldo) = prologue(X): materialise an activation descriptor */
+int pdr_apply_act(const pdr_layer_in_t *in, long P, int C, float *out, int ldo,
+                  pdr_stream_t stream);
+/* GroupNorm(G groups over the first Cn of C channels; the rest pass through), n elements
+ * per channel per batch element -> scale, shift (B,C) */
+int pdr_gn_finalize(const double *chan_stats, int B, int C, int Cn, int G, double n, float eps,
+                    const float *gamma, const float *beta, float *scale, float *shift,
+                    pdr_stream_t stream);
+/* out (B,m,K, Cs+3[+3][+3]) = [feats[idx] | rel | abs | centre]; feats (B,n,Cs) channel-last */
+int pdr_group_build(const float *feats, int Cs, const float *xyz, const float *new_xyz,
+                    const int *idx, const int *counts, int B, int n, int m, int K,
+                    int patch_empty, int with_abs, int with_centre, float *out,
+                    pdr_stream_t stream);
+/* out (B,n1,K, C+11) = [feats_y[idx] | d2 | w | nn_abs | nn_rel | x]; idx int64 (B,n1,K) */
+int pdr_knn_build(const float *feats_y, int C, const float *x, const float *y,
+                  const long long *idx, const float *d2, int B, int n1, int n2, int K,
+                  float *out, pdr_stream_t stream);
+/* out (B*npoint, D) = sum_k softmax_k(mask(scores)) * act(values*vscale+vshift);
+ * scores/values (B*npoint*K, D) with leading dims lds/ldv; counts (B,npoint) or NULL = 'all' */
+int pdr_attention_pool(const float *scores, int lds, const float *values, int ldv,
+                       const float *vscale, const float *vshift, int v_relu, const int *counts,
+                       int B, int npoint, int K, int D, float *out, pdr_stream_t stream);
+/* out (B,m,C) = src (B,n,C)[idx (B,m)] */
+int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m, float *out,
+                    pdr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

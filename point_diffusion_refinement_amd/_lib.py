@@ -38,7 +38,26 @@ SIGNATURES = {
     "pdr_matchcost": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pdr_matchcost_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pdr_emd_cost": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "pdr_fused_layer_tile_rows": (_I, [_I]),
+    "pdr_fused_layer": (_I, [_P, _c.c_long, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "pdr_gn_reduce": (_I, [_P, _I, _I, _I, _I, _c.c_double, _P, _I, _I, _P]),
+    "pdr_apply_act": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
+    "pdr_gn_finalize": (_I, [_P, _I, _I, _I, _I, _c.c_double, _F, _P, _P, _P, _P, _P]),
+    "pdr_group_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pdr_knn_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_attention_pool": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
 }
+
+
+class Seg(_c.Structure):
+    _fields_ = [("ptr", _P), ("C", _I), ("ld", _I), ("row_div", _I)]
+
+
+class LayerIn(_c.Structure):
+    """pdr_layer_in_t of include/pdr_hip.h."""
+    _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("radd", _P),
+                ("add_ld", _I), ("radd_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I)]
 
 _lib = None
 

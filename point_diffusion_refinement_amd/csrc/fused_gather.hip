@@ -1,0 +1,187 @@
+// fused_gather.hip -- channel-last neighbourhood assembly and attention pooling.
+//
+// group_build : QueryAndGroup.forward (reference pointnet2_utils.py:332-438) in one pass:
+//               G[b,j,k,:] = [ feats[b, idx[b,j,k], :] | rel xyz | abs xyz | centre xyz ]
+//               with the subset=False patch (no neighbour -> the query itself, zero feature).
+//               The reference runs group_points twice + 3 elementwise passes + 2 torch.cat over
+//               the K-times expanded tensor.
+// knn_build   : group_knn (pointnet2_utils.py:487-514):
+//               G[b,i,k,:] = [ feats_y[b, idx, :] | d2 | w | nn_abs | nn_rel | x ],
+//               w = (1/(d2+1e-8)) / sum_k (1/(d2_k+1e-8))   (SQUARED distances, as the reference).
+// attention_pool : tail of AttentionModule.forward (attention.py:83-96): count mask (-1e9),
+//               softmax over the K neighbours, value = relu(GN(conv(h))) folded as scale/shift,
+//               weighted sum -> (B*npoint, D).
+// All tensors channel-LAST: a position's channels are contiguous, so neighbour feature rows are
+// read as whole contiguous segments and every store is coalesced.
+#include "pdr_common.h"
+
+namespace {
+
+// one thread per output element e = p * Cout + c
+__global__ __launch_bounds__(256) void group_build_kernel(
+    const float* __restrict__ feats, int Cs, int n, const float* __restrict__ xyz,
+    const float* __restrict__ new_xyz, const int* __restrict__ idx, const int* __restrict__ counts,
+    int m, int K, int patch_empty, int with_abs, int with_centre, long total, int Cout,
+    float* __restrict__ out) {
+  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long p = e / Cout;
+  const int c = static_cast<int>(e - p * Cout);
+  const long bj = p / K;                 // b * m + j
+  const int b = static_cast<int>(bj / m);
+  const int a = idx[p];
+  const bool empty = patch_empty && counts[bj] <= 0;
+  float v;
+  if (c < Cs) {
+    v = empty ? 0.0f : feats[(static_cast<long>(b) * n + a) * Cs + c];
+  } else {
+    const int g = c - Cs;                // 0..2 rel, 3..5 abs, then centre
+    const int d = g % 3;
+    const float ctr = new_xyz[bj * 3 + d];
+    const float ab = empty ? ctr : xyz[(static_cast<long>(b) * n + a) * 3 + d];
+    const int kind = g / 3;              // 0 rel, 1 abs|centre, 2 centre
+    if (kind == 0) v = ab - ctr;
+    else if (kind == 1) v = with_abs ? ab : ctr;
+    else v = ctr;
+  }
+  out[e] = v;
+}
+
+__global__ __launch_bounds__(256) void knn_build_kernel(
+    const float* __restrict__ feats_y, int C, int n2, const float* __restrict__ x,
+    const float* __restrict__ y, const long long* __restrict__ idx, const float* __restrict__ d2,
+    int n1, int K, long total, int Cout, float* __restrict__ out) {
+  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long p = e / Cout;               // (b, i, k)
+  const int c = static_cast<int>(e - p * Cout);
+  const long bi = p / K;
+  const int b = static_cast<int>(bi / n1);
+  const long a = idx[p];
+  float v;
+  if (c < C) {
+    v = feats_y[(static_cast<long>(b) * n2 + a) * C + c];
+  } else if (c == C) {
+    v = d2[p];
+  } else if (c == C + 1) {
+    float norm = 0.0f;
+    for (int k = 0; k < K; ++k) norm += 1.0f / (d2[bi * K + k] + 1e-8f);
+    v = (1.0f / (d2[p] + 1e-8f)) / norm;
+  } else {
+    const int g = c - C - 2;             // 0..2 nn_abs, 3..5 nn_rel, 6..8 x
+    const int d = g % 3;
+    const float xq = x[bi * 3 + d];
+    const float ab = y[(static_cast<long>(b) * n2 + a) * 3 + d];
+    v = g < 3 ? ab : (g < 6 ? ab - xq : xq);
+  }
+  out[e] = v;
+}
+
+// thread per (row = b*npoint + j, d); lanes run over d -> coalesced reads of scores/values
+__global__ __launch_bounds__(256) void attention_pool_kernel(
+    const float* __restrict__ scores, int lds, const float* __restrict__ values, int ldv,
+    const float* __restrict__ vscale, const float* __restrict__ vshift, int v_relu,
+    const int* __restrict__ counts, int K, int D, int npoint, long rows, float* __restrict__ out) {
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= rows * D) return;
+  const long row = t / D;
+  const int d = static_cast<int>(t - row * D);
+  const int b = static_cast<int>(row / npoint);
+  int cnt = K;
+  if (counts) {
+    cnt = counts[row];
+    cnt = cnt < 1 ? 1 : cnt;             // attention.py:85 clamp(min=1)
+  }
+  const float sc = vscale ? vscale[static_cast<long>(b) * D + d] : 1.0f;
+  const float sh = vshift ? vshift[static_cast<long>(b) * D + d] : 0.0f;
+  const float* s = scores + row * K * lds + d;
+  const float* v = values + row * K * ldv + d;
+  float mx = -__builtin_inff();
+  for (int k = 0; k < K; ++k) {
+    const float sk = k < cnt ? s[static_cast<long>(k) * lds] : -1e9f;
+    mx = fmaxf(mx, sk);
+  }
+  float den = 0.0f, num = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    const float sk = k < cnt ? s[static_cast<long>(k) * lds] : -1e9f;
+    const float w = expf(sk - mx);
+    float val = __builtin_fmaf(v[static_cast<long>(k) * ldv], sc, sh);
+    if (v_relu) val = fmaxf(val, 0.0f);
+    den += w;
+    num = __builtin_fmaf(val, w, num);
+  }
+  out[t] = num / den;
+}
+
+// rows of a channel-last matrix: out[b, j, :] = src[b, idx[b,j], :]
+__global__ __launch_bounds__(256) void gather_rows_cl_kernel(const float* __restrict__ src, int n,
+                                                             int C, const int* __restrict__ idx,
+                                                             int m, long total,
+                                                             float* __restrict__ out) {
+  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long bj = e / C;
+  const int c = static_cast<int>(e - bj * C);
+  const int b = static_cast<int>(bj / m);
+  out[e] = src[(static_cast<long>(b) * n + idx[bj]) * C + c];
+}
+
+inline unsigned blocks_for(long total) { return static_cast<unsigned>((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int pdr_group_build(const float* feats, int Cs, const float* xyz, const float* new_xyz,
+                               const int* idx, const int* counts, int B, int n, int m, int K,
+                               int patch_empty, int with_abs, int with_centre, float* out,
+                               pdr_stream_t stream) {
+  if (B < 0 || n <= 0 || m < 0 || K <= 0 || Cs < 0) return PDR_EINVAL;
+  if (B == 0 || m == 0) return PDR_OK;
+  if (!xyz || !new_xyz || !idx || !out || (Cs > 0 && !feats) || (patch_empty && !counts))
+    return PDR_EINVAL;
+  const int Cout = Cs + 3 + (with_abs ? 3 : 0) + (with_centre ? 3 : 0);
+  const long total = static_cast<long>(B) * m * K * Cout;
+  // channel order after the features: rel | (abs) | (centre); the kernel's `kind` 1 slot is abs
+  // when with_abs else centre
+  hipLaunchKernelGGL(group_build_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream),
+                     feats, Cs, n, xyz, new_xyz, idx, counts, m, K, patch_empty, with_abs, with_centre,
+                     total, Cout, out);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_knn_build(const float* feats_y, int C, const float* x, const float* y,
+                             const long long* idx, const float* d2, int B, int n1, int n2, int K,
+                             float* out, pdr_stream_t stream) {
+  if (B < 0 || n1 < 0 || n2 <= 0 || K <= 0 || C < 0) return PDR_EINVAL;
+  if (B == 0 || n1 == 0) return PDR_OK;
+  if (!x || !y || !idx || !d2 || !out || (C > 0 && !feats_y)) return PDR_EINVAL;
+  const int Cout = C + 11;
+  const long total = static_cast<long>(B) * n1 * K * Cout;
+  hipLaunchKernelGGL(knn_build_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream),
+                     feats_y, C, n2, x, y, idx, d2, n1, K, total, Cout, out);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_attention_pool(const float* scores, int lds, const float* values, int ldv,
+                                  const float* vscale, const float* vshift, int v_relu,
+                                  const int* counts, int B, int npoint, int K, int D, float* out,
+                                  pdr_stream_t stream) {
+  if (B < 0 || npoint < 0 || K <= 0 || D <= 0) return PDR_EINVAL;
+  if (B == 0 || npoint == 0) return PDR_OK;
+  if (!scores || !values || !out) return PDR_EINVAL;
+  const long rows = static_cast<long>(B) * npoint;
+  hipLaunchKernelGGL(attention_pool_kernel, dim3(blocks_for(rows * D)), dim3(256), 0,
+                     pdr::as_stream(stream), scores, lds, values, ldv, vscale, vshift, v_relu, counts, K,
+                     D, npoint, rows, out);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_gather_rows(const float* src, const int* idx, int B, int n, int C, int m,
+                               float* out, pdr_stream_t stream) {
+  if (B < 0 || n <= 0 || C <= 0 || m < 0) return PDR_EINVAL;
+  if (B == 0 || m == 0) return PDR_OK;
+  if (!src || !idx || !out) return PDR_EINVAL;
+  const long total = static_cast<long>(B) * m * C;
+  hipLaunchKernelGGL(gather_rows_cl_kernel, dim3(blocks_for(total)), dim3(256), 0,
+                     pdr::as_stream(stream), src, n, C, idx, m, total, out);
+  return pdr::check_launch();
+}

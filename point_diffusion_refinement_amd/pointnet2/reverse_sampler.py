@@ -43,15 +43,17 @@ class GraphedReverseSampler:
 
     # ------------------------------------------------------------------ one step
     def _step(self):
-        t = self._t                                   # () int64 on device
+        t = self._t                                   # (1,) int64 on device
         ts = t.to(torch.float32).expand(self._x.shape[0])
         eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
-        x = (self._x - self.c_eps[t] * eps) / self.sqrt_alpha[t]
+        # index_select keeps the lookup on the device (tensor[t] with a 0-d index would call .item())
+        c_eps, sqrt_a, sigma = (tab.index_select(0, t) for tab in (self.c_eps, self.sqrt_alpha, self.sigma))
+        x = (self._x - c_eps * eps) / sqrt_a
         if self.noise == 'device':
             z = torch.randn_like(x)
         else:
             z = self._z
-        self._x.copy_(x + self.sigma[t] * z)
+        self._x.copy_(x + sigma * z)
         self._t.sub_(1)
 
     def _prepare(self, size, condition, label):
@@ -63,7 +65,7 @@ class GraphedReverseSampler:
             self._z = torch.empty(size, device=self.device)
             self._cond = torch.empty_like(condition, device=self.device)
             self._label = None if label is None else torch.empty_like(label, device=self.device)
-            self._t = torch.zeros((), dtype=torch.int64, device=self.device)
+            self._t = torch.zeros((1,), dtype=torch.int64, device=self.device)
         self._cond.copy_(condition)
         if label is not None:
             self._label.copy_(label)
@@ -87,7 +89,7 @@ class GraphedReverseSampler:
     _CACHE_ATTRS = ("l_uvw", "encoder_cond_features", "decoder_cond_features")
 
     def _cache_tensors(self):
-        net = self.net
+        net = getattr(self.net, "net", self.net)       # FusedCloudConditionNet wraps the torch module
         items = [net.global_feature]
         for name in self._CACHE_ATTRS:
             items.extend(getattr(net, name) or [])
@@ -96,7 +98,7 @@ class GraphedReverseSampler:
     def _adopt_cache(self):
         """A new batch produced fresh retained features; move their VALUES into the tensors the captured
         graph reads and point the network back at those."""
-        net = self.net
+        net = getattr(self.net, "net", self.net)
         fresh = self._cache_tensors()
         assert len(fresh) == len(self._static_cache)
         for dst, src in zip(self._static_cache, fresh):
@@ -125,6 +127,8 @@ class GraphedReverseSampler:
         self._advance_eager()                          # first step: condition branch runs and is retained
         if self._graph is not None:
             self._adopt_cache()
+        if hasattr(self.net, "sync_condition"):
+            self.net.sync_condition()                  # fused network: refresh its channel-last copies in place
 
     def _draw_cpu_noise(self):
         # reference order: one draw per step with t > 0, none at t = 0

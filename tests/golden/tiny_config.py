@@ -37,3 +37,12 @@ def tiny_pointnet_config(include_t=True, point_upsample_factor=1):
         cfg["point_upsample_factor"] = point_upsample_factor
         cfg["include_displacement_center_to_final_output"] = False
     return copy.deepcopy(cfg)
+
+
+def small_fused_config(include_t=True):
+    """Like tiny_pointnet_config but every level keeps >= 32 points, the granularity the fused
+    channel-last kernels tile over (the shipped configs' smallest level is 64 x K=1)."""
+    cfg = tiny_pointnet_config(include_t=include_t)
+    for key in ("architecture", "condition_net_architecture"):
+        cfg[key]["npoint"] = [128, 64, 32, 32]
+    return cfg

@@ -1,0 +1,139 @@
+"""The fused channel-last execution (libpdr_hip.so fused_layer / group_build / attention_pool ...)
+must reproduce the layer-by-layer PyTorch execution of the same network -- which itself is pinned
+to the reference's Python by tests/test_reference_golden.py."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.det_weights import fill_deterministic
+from tests.golden.tiny_config import small_fused_config
+
+from point_diffusion_refinement_amd import _lib
+from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
+from point_diffusion_refinement_amd.pointnet2 import util
+from point_diffusion_refinement_amd.pointnet2.configs import ddpm_pointnet_config, synthetic_batch
+from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedReverseSampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(((a - b).abs() / (b.abs() + 1.0)).max())
+
+
+@pytest.mark.parametrize("P,Cin,Cout,rpb", [(256, 13, 96, 128), (512, 79, 35, 64), (1024, 331, 331, 256),
+                                            (96, 3, 32, 32), (4096, 64, 32, 4096), (2048, 163, 3, 1024)])
+def test_fused_layer_matches_torch(cuda, P, Cin, Cout, rpb):
+    g = torch.Generator().manual_seed(P + Cin)
+    B = P // rpb
+    c1 = Cin // 2 if Cin > 4 else Cin
+    K = 4
+    q = torch.randn(P // K, c1, generator=g).to(cuda)                     # broadcast segment (row_div = K)
+    k = torch.randn(P, Cin - c1 + 5, generator=g).to(cuda)               # strided segment (ld > C)
+    scale, shift, add = (torch.randn(B, Cin, generator=g).to(cuda) for _ in range(3))
+    radd = torch.randn(P, Cin + 2, generator=g).to(cuda)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    bias = torch.randn(Cout, generator=g).to(cuda)
+    segs = [(q, 0, c1, c1, K)] + ([(k, 3, Cin - c1, Cin - c1 + 5, 1)] if Cin > c1 else [])
+    for pre, post in ((False, True), (True, False)):
+        act = FN.Act(segs, P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin, radd=(radd, 1, Cin + 2),
+                     pre_relu=pre, post_relu=post)
+        conv = FN.Conv.__new__(FN.Conv)
+        conv.Wt, conv.bias, conv.Cin, conv.Cout = W.t().contiguous(), bias, Cin, Cout
+        Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=Cout // 2)
+        x = torch.cat([q.repeat_interleave(K, 0)] + ([k[:, 3:3 + Cin - c1]] if Cin > c1 else []), 1)
+        bidx = torch.arange(P, device=cuda) // rpb
+        if pre:
+            x = x.relu()
+        x = x * scale[bidx] + shift[bidx]
+        if post:
+            x = x.relu()
+        x = x + add[bidx] + radd[:, 1:1 + Cin]
+        ref = (x.double() @ W.t().double() + bias.double())
+        assert _rel(Y.double(), ref) < 2e-5
+        np.testing.assert_allclose(FN.materialize(act).cpu().numpy(), x.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        f = ref.clone()
+        f[:, Cout // 2:] = f[:, Cout // 2:].relu()
+        s1 = f.view(B, rpb, Cout).sum(1)
+        s2 = (f * f).view(B, rpb, Cout).sum(1)
+        got = part.view(B, tpb, Cout, 2).double().sum(1)
+        assert _rel(got[..., 0], s1) < 1e-4 and _rel(got[..., 1], s2) < 1e-4
+
+
+def test_groupnorm_fold_matches_torch_groupnorm(cuda):
+    g = torch.Generator().manual_seed(3)
+    B, rpb, C = 3, 256, 79                                               # MyGroupNorm(32, 79): 64 normalised + 15 pass-through
+    x = (torch.randn(B * rpb, C, generator=g) * 2 + 0.7).to(cuda)
+    from point_diffusion_refinement_amd.pointnet2_ops.attention import MyGroupNorm
+    gn = fill_deterministic(MyGroupNorm(32, C), 9).to(cuda)
+    ident = FN.Conv.__new__(FN.Conv)
+    ident.Wt, ident.bias, ident.Cin, ident.Cout = torch.eye(C, device=cuda), torch.zeros(C, device=cuda), C, C
+    Y, part, tpb = FN.run_layer(FN.plain(x, B, rpb), ident, stats=True)
+    scale, shift = FN.Norm(gn).fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
+    got = FN.materialize(FN.Act([(Y, 0, C, C, 1)], B * rpb, B, rpb, scale=scale, shift=shift))
+    want = gn(x.view(B, rpb, C).permute(0, 2, 1).unsqueeze(-1)).squeeze(-1).permute(0, 2, 1).reshape(B * rpb, C)
+    np.testing.assert_allclose(got.cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def _pair(cfg, seed, device):
+    net = fill_deterministic(PointNet2CloudCondition(cfg), seed).eval().to(device)
+    return net, FN.FusedCloudConditionNet(net)
+
+
+def _cached_eps(net, fused, x, cond, ts, label):
+    with torch.no_grad():
+        net.reset_cond_features()
+        net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)       # fills the cache
+        x2 = x * 0.9
+        ref = net(x2, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+        fused.sync_condition()
+        got = fused(x2, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+    return got, ref
+
+
+def test_fused_network_small_config(cuda):
+    net, fused = _pair(small_fused_config(), 21, cuda)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 3, generator=g).to(cuda)
+    cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
+    ts, label = torch.tensor([9.0, 4.0], device=cuda), torch.tensor([1, 7], device=cuda)
+    got, ref = _cached_eps(net, fused, x, cond, ts, label)
+    err = ((got - ref).abs() / (ref.abs() + 1.0))
+    assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
+
+
+def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)            # default (random) init
+    fused = FN.FusedCloudConditionNet(net)
+    x, cond, label = synthetic_batch(2, seed=3, device=cuda)
+    ts = torch.tensor([500.0, 20.0], device=cuda)
+    got, ref = _cached_eps(net, fused, x, cond, ts, label)
+    err = ((got - ref).abs() / (ref.abs() + 1.0))
+    assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
+
+    # reverse sampler: fused + hipGraph replay vs the reference-style eager loop, same CPU noise stream
+    dh = util.calc_diffusion_hyperparams(6, 1e-4, 0.02)
+    util.set_device(cuda)
+    util.set_noise_source('cpu')
+    torch.manual_seed(77)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        want = util.sampling(net, (2, 2048, 3), dh, label=label, verbose=False, condition=cond)
+    util.set_device(None)
+    for use_graph in (False, True):
+        sampler = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=use_graph)
+        torch.manual_seed(77)
+        got = sampler.sample((2, 2048, 3), cond, label)
+        rel = ((got - want).abs() / (want.abs() + 1.0))
+        assert rel.max() < 1e-3 and (rel < 1e-4).float().mean() > 0.99, (use_graph, rel.max())
+    # a second batch through the SAME captured graph (retained features are re-pointed in place)
+    x2, cond2, label2 = synthetic_batch(2, seed=4, device=cuda)
+    torch.manual_seed(78)
+    a = sampler.sample((2, 2048, 3), cond2, label2)
+    torch.manual_seed(78)
+    b = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=False).sample((2, 2048, 3), cond2, label2)
+    assert ((a - b).abs() / (b.abs() + 1.0)).max() < 1e-3
