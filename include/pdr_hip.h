@@ -173,13 +173,14 @@ typedef struct {
   int add_ld;
   int radd_ld;
   int pre_relu, post_relu;
-  int rows_per_batch;   /* npoint*K; must be a multiple of 32 */
+  int rows_per_batch;   /* npoint*K: positions per batch element (one GroupNorm instance) */
 } pdr_layer_in_t;
 
-/* rows per workgroup tile chosen for `rows_per_batch` (128/64/32; 0 = unsupported) */
+/* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into
+ * ceil(rows_per_batch / tile) tiles, the last one possibly partial */
 int pdr_fused_layer_tile_rows(int rows_per_batch);
 /* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight
- * transposed), exact fp32 MFMA.  partial: NULL or (P/tile_rows, Cout, 2) floats receiving the
+ * transposed), exact fp32 MFMA.  partial: NULL or (B*tiles_per_batch, Cout, 2) floats receiving the
  * per-tile sum / sum of squares of y (columns >= relu_col0: of relu(y)). */
 int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,

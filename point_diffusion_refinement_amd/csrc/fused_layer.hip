@@ -74,8 +74,13 @@ __global__ __launch_bounds__(256) void fused_layer_kernel(
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int rw = wave % RW, cw = wave / RW;
-  const long row0 = static_cast<long>(blockIdx.x) * TM;
-  const int b = static_cast<int>(row0 / in.rows_per_batch);   // tile never straddles a batch
+  // tiles are cut per batch element (a tile never straddles two GroupNorm instances); the last
+  // tile of a batch element may be partial
+  const int tpb = (in.rows_per_batch + TM - 1) / TM;
+  const int b = blockIdx.x / tpb;
+  const int tb = blockIdx.x - b * tpb;
+  const long row0 = static_cast<long>(b) * in.rows_per_batch + static_cast<long>(tb) * TM;
+  const int nvalid = min(TM, in.rows_per_batch - tb * TM);
   const float* sc = in.scale ? in.scale + static_cast<long>(b) * Cin : nullptr;
   const float* sh = in.shift ? in.shift + static_cast<long>(b) * Cin : nullptr;
   const float* ad = in.add ? in.add + static_cast<long>(b) * in.add_ld : nullptr;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void fused_layer_kernel(
           const int r = (tid >> 5) + 8 * i;
           const long row = row0 + r;
           float v = 0.0f;
-          if (cok && row < P) {
+          if (cok && r < nvalid) {
             v = load_a(in, row, c, b);
             if (in.pre_relu) v = fmaxf(v, 0.0f);
             v = __builtin_fmaf(v, s, h);
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void fused_layer_kernel(
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
         const long row = row0 + rw * 32 + rr;
         const float y = acc[t][r] + bv;
-        if (colok && row < P) {
+        if (colok && rw * 32 + rr < nvalid) {
           Y[row * ldy + col] = y;
           const float f = relu_stat ? fmaxf(y, 0.0f) : y;
           s1 += f;
@@ -259,10 +264,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 
 extern "C" int pdr_fused_layer_tile_rows(int rows_per_batch) {
   if (rows_per_batch <= 0) return 0;
-  if (rows_per_batch % 128 == 0) return 128;
-  if (rows_per_batch % 64 == 0) return 64;
-  if (rows_per_batch % 32 == 0) return 32;
-  return 0;
+  if (rows_per_batch >= 128) return 128;
+  if (rows_per_batch >= 64) return 64;
+  return 32;
 }
 
 // Y (P, Cout; leading dim ldy) = prologue(X) . Wt + bias.  partial: NULL or
@@ -281,9 +285,10 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   }
   if (ctot != Cin) return PDR_EINVAL;
   const int tm = pdr_fused_layer_tile_rows(in->rows_per_batch);
-  if (tm == 0 || P % in->rows_per_batch != 0) return PDR_EUNSUPPORTED;
+  if (tm == 0 || P % in->rows_per_batch != 0) return PDR_EINVAL;
   hipStream_t s = pdr::as_stream(stream);
-  const dim3 grid(static_cast<unsigned>(P / tm));
+  const long nb = P / in->rows_per_batch;
+  const dim3 grid(static_cast<unsigned>(nb * ((in->rows_per_batch + tm - 1) / tm)));
   if (tm == 128)
     hipLaunchKernelGGL(fused_layer_kernel<128>, grid, dim3(256), 0, s, *in, P, Cin, Wt, bias, Cout, Y,
                        ldy, partial, relu_col0);

@@ -96,17 +96,16 @@ def run_layer(act, conv, stats=False, relu_col0=None):
     assert act.C == conv.Cin, (act.C, conv.Cin)
     Y = torch.empty((act.P, conv.Cout), dtype=torch.float32, device=conv.Wt.device)
     tm = lib.pdr_fused_layer_tile_rows(act.rpb)
-    if tm == 0:
-        raise NotImplementedError("rows per batch element (%d) must be a multiple of 32" % act.rpb)
+    tpb = (act.rpb + tm - 1) // tm
     partial = None
     if stats:
-        partial = torch.empty((act.P // tm, conv.Cout, 2), dtype=torch.float32, device=Y.device)
+        partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
     _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.bias.data_ptr(),
                                    conv.Cout, Y.data_ptr(), conv.Cout,
                                    partial.data_ptr() if stats else None,
                                    conv.Cout if relu_col0 is None else relu_col0, _stream()), "fused_layer")
-    return Y, partial, act.rpb // tm
+    return Y, partial, tpb
 
 
 def materialize(act):

@@ -25,7 +25,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("P,Cin,Cout,rpb", [(256, 13, 96, 128), (512, 79, 35, 64), (1024, 331, 331, 256),
-                                            (96, 3, 32, 32), (4096, 64, 32, 4096), (2048, 163, 3, 1024)])
+                                            (96, 3, 32, 32), (4096, 64, 32, 4096), (2048, 163, 3, 1024),
+                                            (64, 35, 44, 16), (600, 20, 70, 200)])
 def test_fused_layer_matches_torch(cuda, P, Cin, Cout, rpb):
     g = torch.Generator().manual_seed(P + Cin)
     B = P // rpb
