@@ -178,11 +178,11 @@ typedef struct {
 
 /* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into
  * ceil(rows_per_batch / tile) tiles, the last one possibly partial */
-int pdr_fused_layer_tile_rows(int rows_per_batch);
+int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
 /* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight
- * transposed), exact fp32 MFMA.  partial: NULL or (B*tiles_per_batch, Cout, 2) floats receiving the
+ * transposed; leading dimension ldw >= Cout), exact fp32 MFMA.  partial: NULL or (B*tiles_per_batch, Cout, 2) floats receiving the
  * per-tile sum / sum of squares of y (columns >= relu_col0: of relu(y)). */
-int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt,
+int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,
                     int relu_col0, pdr_stream_t stream);
 /* chan_stats[b, coff+c] (double sum, double sumsq) = mult * sum over tiles of batch b;

@@ -35,140 +35,255 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KC = 32;    // K-chunk (input channels per LDS stage)
-constexpr int TN = 128;   // output columns per pass
-constexpr int PAD = 1;
+// resolved source of ONE input channel (a thread's column is fixed within a K-chunk)
+struct ColSrc {
+  const float* ptr;  // segment base + channel offset
+  int ld;
+  int shift;         // log2(row_div): neighbour-broadcast divisors are powers of two here
+};
 
-__device__ __forceinline__ float load_a(const pdr_layer_in_t& in, long row, int c, int b) {
-  // segment lookup (n_seg <= 4, wave-uniform per c only when KC-aligned; kept branchy but tiny)
+__device__ __forceinline__ ColSrc resolve_col(const pdr_layer_in_t& in, int c) {
+  ColSrc r;
+  r.ptr = in.seg[0].ptr;
+  r.ld = in.seg[0].ld;
+  r.shift = 0;
   int c0 = 0;
-  float v = 0.0f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (s < in.n_seg) {
       const int cs = in.seg[s].C;
       if (c >= c0 && c < c0 + cs) {
-        const long srow = in.seg[s].row_div == 1 ? row : row / in.seg[s].row_div;
-        v = in.seg[s].ptr[srow * in.seg[s].ld + (c - c0)];
+        r.ptr = in.seg[s].ptr + (c - c0);
+        r.ld = in.seg[s].ld;
+        r.shift = __builtin_ctz(in.seg[s].row_div);
       }
       c0 += cs;
     }
   }
-  return v;
+  return r;
 }
 
-// TM in {128, 64, 32}: rows per workgroup.  Wave w owns row block (w % RW) and column
-// group (w / RW) where RW = TM/32; each wave computes 32 rows x (TN / CW) columns.
-template <int TM>
-__global__ __launch_bounds__(256) void fused_layer_kernel(
-    pdr_layer_in_t in, long P, int Cin, const float* __restrict__ Wt, const float* __restrict__ bias,
-    int Cout, float* __restrict__ Y, int ldy, float* __restrict__ partial, int relu_col0) {
-  constexpr int RW = TM / 32;        // row-waves
-  constexpr int CW = 4 / RW;         // column-waves
-  constexpr int NT = TN / 32 / CW;   // 32-col MFMA tiles per wave
-  __shared__ float As[KC][TM + PAD];
-  __shared__ float Bs[KC][TN + PAD];
-  __shared__ float red[4][TN][2];    // cross-row-wave stats reduction
+__device__ __forceinline__ float load_col(const ColSrc& s, long row) {
+  return s.ptr[(row >> s.shift) * s.ld];
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int rw = wave % RW, cw = wave / RW;
-  // tiles are cut per batch element (a tile never straddles two GroupNorm instances); the last
-  // tile of a batch element may be partial
-  const int tpb = (in.rows_per_batch + TM - 1) / TM;
-  const int b = blockIdx.x / tpb;
-  const int tb = blockIdx.x - b * tpb;
-  const long row0 = static_cast<long>(b) * in.rows_per_batch + static_cast<long>(tb) * TM;
-  const int nvalid = min(TM, in.rows_per_batch - tb * TM);
-  const float* sc = in.scale ? in.scale + static_cast<long>(b) * Cin : nullptr;
-  const float* sh = in.shift ? in.shift + static_cast<long>(b) * Cin : nullptr;
-  const float* ad = in.add ? in.add + static_cast<long>(b) * in.add_ld : nullptr;
+// ---------------------------------------------------------------------------------------------
+// Block tile TM x TN = (WR*RT*32) x (WC*CT*32); wave (wr, wc) owns RT x CT MFMA tiles of 32x32.
+// grid.x strides over the row tiles (cut per batch element), grid.y = column blocks.
+// K is walked segment by segment in chunks of KC channels, so within a chunk the source
+// pointer / leading dimension / broadcast shift are wave-uniform (scalar registers) and every A
+// load is `scalar base + 32-bit lane offset`.
+// Pipeline per chunk: global -> registers (prologue applied) is issued BEFORE the MFMAs of the
+// previous chunk, registers -> LDS after them: the loads overlap the matrix pipe.
+template <int RT, int CT, int WR, int WC, int KC, bool RADD>
+__global__ __launch_bounds__(256, 2) void fused_layer_kernel(
+    pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
+    const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
+    float* __restrict__ partial, int relu_col0, int n_row_tiles) {
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
+  constexpr int APT = TM * KC / 256;   // A elements per thread per chunk
+  constexpr int WPT = (KC * TN + 255) / 256;   // W elements per thread per chunk
+  constexpr int RSTEP = 256 / KC;      // row stride between a thread's A elements
+  __shared__ float As[KC][TM + 1];
+  __shared__ float Bs[KC][TN + 1];
+  __shared__ float red[WR][TN][2];
 
-  for (int n0 = 0; n0 < Cout; n0 += TN) {
-    f32x16 acc[NT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave % WR, wc = wave / WR;
+  const int il = lane & 31, hi = lane >> 5;
+  const int rpb = in.rows_per_batch;
+  const int tpb = (rpb + TM - 1) / TM;
+  const int n0 = blockIdx.y * TN;
+  const int ac_ = tid % KC, ar0_ = tid / KC;        // this thread's A column-in-chunk / first row
+  // W chunk element e = tid + 256 i  ->  (row e / TN, column e % TN); TN need not divide 256
+  const float lo_pre = in.pre_relu ? 0.0f : -__builtin_inff();
+  const float lo_post = in.post_relu ? 0.0f : -__builtin_inff();
+  const bool single_chunk = in.n_seg == 1 && Cin <= KC;   // W staged once per workgroup
+  bool w_loaded = false;
+
+  float bias_r[CT];   // this lane's bias per column tile (the column block is fixed per workgroup)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  for (int j = 0; j < CT; ++j) {
+    const int col = n0 + (wc * CT + j) * 32 + il;
+    bias_r[j] = (bias && col < Cout) ? bias[col] : 0.0f;
+  }
+  float ra[APT], rw[WPT];
+  float rr[RADD ? APT : 1];
+  float f_s = 1.0f, f_h = 0.0f, f_a = 0.0f;   // prologue parameters of the chunk in flight
+  bool f_cok = false;
+  int f_kmax = 0;
 
-    for (int k0 = 0; k0 < Cin; k0 += KC) {
+  for (int tile = blockIdx.x; tile < n_row_tiles; tile += gridDim.x) {
+    const int b = tile / tpb, tb = tile - b * tpb;
+    const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
+    const int nvalid = min(TM, rpb - tb * TM);
+    const float* sc_b = in.scale ? in.scale + static_cast<long>(b) * Cin : nullptr;
+    const float* sh_b = in.shift ? in.shift + static_cast<long>(b) * Cin : nullptr;
+    const float* ad_b = in.add ? in.add + static_cast<long>(b) * in.add_ld : nullptr;
+    const float* rd_b = in.radd ? in.radd + row0 * in.radd_ld : nullptr;
+
+    // fetch(): ONLY address arithmetic + loads -- nothing consumes a loaded value, so no
+    // s_waitcnt is emitted and the loads stay in flight across the MFMA loop that follows.
+    // commit(): prologue math on the arrived values + LDS stores.
+    // (sg, ks, cbase): segment, channel offset inside it, global channel index of its first channel
+    auto fetch = [&](int sg, int ks, int cbase) {
+      // `opaque`: re-materialise the per-thread indices on every call.  Without it LLVM hoists the
+      // 2 x (APT + WPT) loop-invariant row / address values out of the chunk loop and keeps them
+      // alive across the MFMA loop (>100 VGPRs, occupancy 1).
+      int ar0 = ar0_, ac = ac_, wt = tid;
+      asm volatile("" : "+v"(ar0), "+v"(ac), "+v"(wt));
+      const pdr_seg_t seg = in.seg[sg];
+      const int shift = __builtin_ctz(seg.row_div);
+      const float* abase = seg.ptr + (row0 >> shift) * seg.ld;      // uniform; row0 % row_div == 0
+      const int cl = ks + ac;                                        // channel inside the segment
+      f_cok = cl < seg.C;
+      const int cc = f_cok ? cl : seg.C - 1;
+      const int cg = cbase + cc;                                     // global input channel
+      // channels beyond the segment read a valid address and are forced to 0 in commit()
+      f_s = sc_b ? sc_b[cg] : 1.0f;
+      f_h = sh_b ? sh_b[cg] : 0.0f;
+      f_a = ad_b ? ad_b[cg] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < APT; ++i) {
+        // rows beyond nvalid re-read the tile's last row; their results are masked in the epilogue
+        const int r = min(ar0 + RSTEP * i, nvalid - 1);
+        ra[i] = abase[(r >> shift) * seg.ld + cc];
+      }
+      if constexpr (RADD) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+          const int r = min(ar0 + RSTEP * i, nvalid - 1);
+          rr[i] = rd_b[r * in.radd_ld + cg];
+        }
+      }
+      f_kmax = min(KC, seg.C - ks);                                  // valid W rows in this chunk
+      if (!(single_chunk && w_loaded)) {
+        const float* wbase = Wt + static_cast<long>(cbase + ks) * ldw + n0;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+          const int e = wt + 256 * i;
+          const int k = e / TN, n = e - k * TN;
+          rw[i] = wbase[min(k, f_kmax - 1) * ldw + min(n, Cout - 1 - n0)];
+        }
+      }
+    };
+    auto commit = [&]() {
+      int ar0 = ar0_, ac = ac_, wt = tid;
+      asm volatile("" : "+v"(ar0), "+v"(ac), "+v"(wt));
+      const float s = f_cok ? f_s : 0.0f, h = f_cok ? f_h : 0.0f, a = f_cok ? f_a : 0.0f;
+      const float rok = f_cok ? 1.0f : 0.0f;
+#pragma unroll
+      for (int i = 0; i < APT; ++i) {
+        float v = fmaxf(ra[i], lo_pre);
+        v = __builtin_fmaf(v, s, h);
+        v = fmaxf(v, lo_post) + a;
+        if constexpr (RADD) v = __builtin_fmaf(rr[i], rok, v);
+        As[ac][ar0 + RSTEP * i] = v;
+      }
+      if (!(single_chunk && w_loaded)) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+          const int e = wt + 256 * i;
+          const int k = e / TN, n = e - k * TN;
+          if (e < KC * TN) Bs[k][n] = (k < f_kmax && n0 + n < Cout) ? rw[i] : 0.0f;
+        }
+        w_loaded = true;
+      }
+    };
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    int sg = 0, ks = 0, cbase = 0;
+    fetch(0, 0, 0);
+    while (true) {
+      __syncthreads();                 // previous chunk's MFMAs (and epilogue reads of `red`) done
+      commit();
       __syncthreads();
-      // ---- stage A (with the fused prologue): thread -> (row = tid/32 + 8 i, c = tid%32)
-      {
-        const int c = k0 + (tid & 31);
-        const bool cok = c < Cin;
-        const float s = (cok && sc) ? sc[c] : 1.0f;
-        const float h = (cok && sh) ? sh[c] : 0.0f;
-        const float a = (cok && ad) ? ad[c] : 0.0f;
-#pragma unroll 4
-        for (int i = 0; i < TM / 8; ++i) {
-          const int r = (tid >> 5) + 8 * i;
-          const long row = row0 + r;
-          float v = 0.0f;
-          if (cok && r < nvalid) {
-            v = load_a(in, row, c, b);
-            if (in.pre_relu) v = fmaxf(v, 0.0f);
-            v = __builtin_fmaf(v, s, h);
-            if (in.post_relu) v = fmaxf(v, 0.0f);
-            v += a;
-            if (in.radd) v += in.radd[row * in.radd_ld + c];
-          }
-          As[tid & 31][r] = v;
-        }
+      const int segC = in.seg[sg].C;
+      const int ksteps = (min(KC, segC - ks) + 1) >> 1;
+      ks += KC;
+      if (ks >= segC) {
+        cbase += segC;
+        ks = 0;
+        ++sg;
       }
-      // ---- stage W chunk: Wt is (Cin, Cout) row-major -> Bs[k][n], coalesced along n
-      {
-#pragma unroll 4
-        for (int i = 0; i < KC * TN / 256; ++i) {
-          const int e = tid + 256 * i;
-          const int k = e / TN, n = e % TN;
-          const bool ok = (k0 + k) < Cin && (n0 + n) < Cout;
-          Bs[k][n] = ok ? Wt[static_cast<long>(k0 + k) * Cout + n0 + n] : 0.0f;
-        }
-      }
-      __syncthreads();
-      // ---- MFMA: A operand lane l -> A[row = l&31][k = 2 kk + (l>>5)], B -> W[k][col = l&31]
-      const int kl = lane >> 5, il = lane & 31;
+      const bool more = sg < in.n_seg;
+      if (more) fetch(sg, ks, cbase);  // in flight during the MFMAs below
+      for (int kk = 0; kk < ksteps; ++kk) {
+        float a[RT], w[CT];
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        const float a = As[2 * kk + kl][rw * 32 + il];
+        for (int i = 0; i < RT; ++i) a[i] = As[2 * kk + hi][(wr * RT + i) * 32 + il];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float w = Bs[2 * kk + kl][(cw * NT + t) * 32 + il];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc[t], 0, 0, 0);
-        }
+        for (int j = 0; j < CT; ++j) w[j] = Bs[2 * kk + hi][(wc * CT + j) * 32 + il];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], w[j], acc[i][j], 0, 0, 0);
       }
+      if (!more) break;
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)
-    const int il = lane & 31, hi = lane >> 5;
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5).
+    // Full row tiles (the common case) store through ONE predicated region per 32-column tile:
+    // per-element conditions would put every store in its own basic block, each opened by an
+    // s_waitcnt vmcnt(0) that drains the previous store (stores count in vmcnt on gfx950).
+    int il_e = il;
+    asm volatile("" : "+v"(il_e));
+    const bool rows_full = nvalid == TM;   // uniform
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = n0 + (cw * NT + t) * 32 + il;
+    for (int j = 0; j < CT; ++j) {
+      const int cl = (wc * CT + j) * 32 + il_e;
+      const int col = n0 + cl;
       const bool colok = col < Cout;
-      const float bv = (colok && bias) ? bias[col] : 0.0f;
+      const float bv = bias_r[j];
       const bool relu_stat = col >= relu_col0;
       float s1 = 0.0f, s2 = 0.0f;
+      float* ybase = Y + row0 * ldy + col;
+      if (colok) {
+        if (rows_full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const long row = row0 + rw * 32 + rr;
-        const float y = acc[t][r] + bv;
-        if (colok && rw * 32 + rr < nvalid) {
-          Y[row * ldy + col] = y;
-          const float f = relu_stat ? fmaxf(y, 0.0f) : y;
-          s1 += f;
-          s2 = __builtin_fmaf(f, f, s2);
+          for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              const float y = acc[i][j][r] + bv;
+              ybase[rl * ldy] = y;
+              const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+              s1 += f;
+              s2 = __builtin_fmaf(f, f, s2);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              const float y = acc[i][j][r] + bv;
+              if (rl < nvalid) {
+                ybase[rl * ldy] = y;
+                const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+                s1 += f;
+                s2 = __builtin_fmaf(f, f, s2);
+              }
+            }
+          }
         }
       }
       if (partial) {
-        // lanes l and l+32 hold the same column: fold, then reduce across the RW row-waves
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (hi == 0) {
-          red[rw][(cw * NT + t) * 32 + il][0] = s1;
-          red[rw][(cw * NT + t) * 32 + il][1] = s2;
+          red[wr][cl][0] = s1;
+          red[wr][cl][1] = s2;
         }
       }
     }
@@ -177,11 +292,11 @@ __global__ __launch_bounds__(256) void fused_layer_kernel(
       if (tid < TN && n0 + tid < Cout) {
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int w = 0; w < RW; ++w) {
+        for (int w = 0; w < WR; ++w) {
           s1 += red[w][tid][0];
           s2 += red[w][tid][1];
         }
-        float* o = partial + (static_cast<long>(blockIdx.x) * Cout + n0 + tid) * 2;
+        float* o = partial + (static_cast<long>(tile) * Cout + n0 + tid) * 2;
         o[0] = s1;
         o[1] = s2;
       }
@@ -189,23 +304,40 @@ __global__ __launch_bounds__(256) void fused_layer_kernel(
   }
 }
 
-// chan_stats[b, coff + c] (double2) = mult * sum over the tiles of batch b of partial[tile, c]
-__global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict__ partial, int ldp,
-                                                        int tiles_per_batch, int C, double mult,
-                                                        double* __restrict__ chan_stats, int Ctot,
-                                                        int coff) {
+// chan_stats[b, coff + c] (double2) = mult * sum over the tiles of batch b of partial[tile, c].
+// 1024 threads = 32 channels x 32 tile-slices: the per-(b,c) sum over up to 512 tiles is split
+// over 32 lanes' worth of independent loads and folded through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void gn_reduce_kernel(const float* __restrict__ partial, int ldp,
+                                                         int tiles_per_batch, int C, double mult,
+                                                         double* __restrict__ chan_stats, int Ctot,
+                                                         int coff) {
+  __shared__ double red[32][32][2];
   const int b = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
-  const float* p = partial + (static_cast<long>(b) * tiles_per_batch * ldp + c) * 2;
-  for (int t = 0; t < tiles_per_batch; ++t) {
-    s1 += p[static_cast<long>(t) * ldp * 2 + 0];
-    s2 += p[static_cast<long>(t) * ldp * 2 + 1];
+  if (c < C) {
+    const float* p = partial + (static_cast<long>(b) * tiles_per_batch * ldp + c) * 2;
+    for (int t = sl; t < tiles_per_batch; t += 32) {
+      const float2 v = *reinterpret_cast<const float2*>(p + static_cast<long>(t) * ldp * 2);
+      s1 += v.x;
+      s2 += v.y;
+    }
   }
-  double* o = chan_stats + (static_cast<long>(b) * Ctot + coff + c) * 2;
-  o[0] = s1 * mult;
-  o[1] = s2 * mult;
+  red[sl][cl][0] = s1;
+  red[sl][cl][1] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      a1 += red[k][cl][0];
+      a2 += red[k][cl][1];
+    }
+    double* o = chan_stats + (static_cast<long>(b) * Ctot + coff + c) * 2;
+    o[0] = a1 * mult;
+    o[1] = a2 * mult;
+  }
 }
 
 // out (P, C; ld ldo) = prologue(X): materialise an activation (needed where the next consumer
@@ -217,7 +349,7 @@ __global__ __launch_bounds__(256) void apply_act_kernel(pdr_layer_in_t in, long 
   const long row = e / C;
   const int c = static_cast<int>(e - row * C);
   const int b = static_cast<int>(row / in.rows_per_batch);
-  float v = load_a(in, row, c, b);
+  float v = load_col(resolve_col(in, c), row);
   if (in.pre_relu) v = fmaxf(v, 0.0f);
   const float s = in.scale ? in.scale[static_cast<long>(b) * C + c] : 1.0f;
   const float h = in.shift ? in.shift[static_cast<long>(b) * C + c] : 0.0f;
@@ -262,42 +394,82 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 
 }  // namespace
 
-extern "C" int pdr_fused_layer_tile_rows(int rows_per_batch) {
-  if (rows_per_batch <= 0) return 0;
-  if (rows_per_batch >= 128) return 128;
-  if (rows_per_batch >= 64) return 64;
-  return 32;
+// Tile shape selection.  Narrow outputs (Cout <= 64) use tall 256-row tiles with all four
+// waves stacked along the rows; wide outputs 128 x 128 tiles (2 x 2 waves); small batch
+// elements (few rows per GroupNorm instance) shrink the row tile.
+namespace {
+// Tile shapes.  "Tall" shapes stack all four waves along the rows and give every wave the full
+// output width (one column block => the input is read exactly once): used whenever Cout <= 160.
+// Wide outputs use 128 x 128 tiles (2 x 2 waves) over a 2-D grid.
+struct TileCfg { int tm, tn, id; };
+inline TileCfg pick_tile(int rows_per_batch, int Cout) {
+  if (rows_per_batch >= 256 && Cout <= 32) return {256, 32, 0};
+  if (rows_per_batch >= 256 && Cout <= 64) return {256, 64, 1};
+  if (rows_per_batch >= 128 && Cout <= 96) return {128, 96, 2};
+  if (rows_per_batch >= 128 && Cout > 128 && Cout <= 160) return {128, 160, 3};
+  if (rows_per_batch >= 128) return {128, 128, 4};
+  if (rows_per_batch >= 64) return {64, 128, 5};
+  return {32, 128, 6};
+}
+}  // namespace
+
+extern "C" int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout) {
+  if (rows_per_batch <= 0 || Cout <= 0) return 0;
+  return pick_tile(rows_per_batch, Cout).tm;
 }
 
 // Y (P, Cout; leading dim ldy) = prologue(X) . Wt + bias.  partial: NULL or
-// (P / tile_rows, Cout, 2) floats receiving per-tile sum / sum of squares of y
+// (B * tiles_per_batch, Cout, 2) floats receiving per-tile sum / sum of squares of y
 // (columns >= relu_col0: of relu(y)).
-extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt,
+extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
                                const float* bias, int Cout, float* Y, int ldy, float* partial,
                                int relu_col0, pdr_stream_t stream) {
-  if (!in || !Wt || !Y || P < 0 || Cin <= 0 || Cout <= 0 || in->n_seg < 1 || in->n_seg > 4)
+  if (!in || !Wt || !Y || P < 0 || Cin <= 0 || Cout <= 0 || in->n_seg < 1 || in->n_seg > 4 ||
+      ldw < Cout || ldy < Cout)
     return PDR_EINVAL;
   if (P == 0) return PDR_OK;
   int ctot = 0;
   for (int s = 0; s < in->n_seg; ++s) {
     if (!in->seg[s].ptr || in->seg[s].C <= 0 || in->seg[s].row_div < 1) return PDR_EINVAL;
+    if (in->seg[s].row_div & (in->seg[s].row_div - 1)) return PDR_EUNSUPPORTED;  // power of two only
     ctot += in->seg[s].C;
   }
-  if (ctot != Cin) return PDR_EINVAL;
-  const int tm = pdr_fused_layer_tile_rows(in->rows_per_batch);
-  if (tm == 0 || P % in->rows_per_batch != 0) return PDR_EINVAL;
+  if (ctot != Cin || in->rows_per_batch <= 0 || P % in->rows_per_batch != 0) return PDR_EINVAL;
+  const TileCfg t = pick_tile(in->rows_per_batch, Cout);
+  for (int sg = 0; sg < in->n_seg; ++sg) {
+    // every tile must start on a multiple of the broadcast divisor
+    const int d = in->seg[sg].row_div;
+    if (in->rows_per_batch % d != 0 || (in->rows_per_batch > t.tm && t.tm % d != 0)) return PDR_EUNSUPPORTED;
+  }
   hipStream_t s = pdr::as_stream(stream);
   const long nb = P / in->rows_per_batch;
-  const dim3 grid(static_cast<unsigned>(nb * ((in->rows_per_batch + tm - 1) / tm)));
-  if (tm == 128)
-    hipLaunchKernelGGL(fused_layer_kernel<128>, grid, dim3(256), 0, s, *in, P, Cin, Wt, bias, Cout, Y,
-                       ldy, partial, relu_col0);
-  else if (tm == 64)
-    hipLaunchKernelGGL(fused_layer_kernel<64>, grid, dim3(256), 0, s, *in, P, Cin, Wt, bias, Cout, Y,
-                       ldy, partial, relu_col0);
-  else
-    hipLaunchKernelGGL(fused_layer_kernel<32>, grid, dim3(256), 0, s, *in, P, Cin, Wt, bias, Cout, Y,
-                       ldy, partial, relu_col0);
+  const long ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
+  const int ncol = (Cout + t.tn - 1) / t.tn;
+  // enough workgroups to fill 256 CUs a few times over; the rest is covered by the grid stride
+  long gx = ntiles;
+  const long cap = (256L * 6 + ncol - 1) / ncol;
+  if (gx > cap) gx = cap;
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
+  const int nt = static_cast<int>(ntiles);
+#define PDR_LAUNCH(RT, CT, WR, WC, KC)                                                              \
+  do {                                                                                               \
+    if (in->radd)                                                                                    \
+      hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, true>), grid, dim3(256), 0, s, *in, \
+                         Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);                  \
+    else                                                                                             \
+      hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false>), grid, dim3(256), 0, s,     \
+                         *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);             \
+  } while (0)
+  switch (t.id) {
+    case 0: PDR_LAUNCH(2, 1, 4, 1, 16); break;
+    case 1: PDR_LAUNCH(2, 2, 4, 1, 16); break;
+    case 2: PDR_LAUNCH(1, 3, 4, 1, 32); break;
+    case 3: PDR_LAUNCH(1, 5, 4, 1, 32); break;
+    case 4: PDR_LAUNCH(2, 2, 2, 2, 32); break;
+    case 5: PDR_LAUNCH(1, 2, 2, 2, 32); break;
+    default: PDR_LAUNCH(1, 1, 1, 4, 32); break;
+  }
+#undef PDR_LAUNCH
   return pdr::check_launch();
 }
 
@@ -307,7 +479,7 @@ extern "C" int pdr_gn_reduce(const float* partial, int ldp, int B, int tiles_per
   if (!partial || !chan_stats || B <= 0 || tiles_per_batch <= 0 || C <= 0 || coff < 0 ||
       coff + C > Ctot || ldp < C)
     return PDR_EINVAL;
-  hipLaunchKernelGGL(gn_reduce_kernel, dim3((C + 255) / 256, B), dim3(256), 0, pdr::as_stream(stream),
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3((C + 31) / 32, B), dim3(1024), 0, pdr::as_stream(stream),
                      partial, ldp, tiles_per_batch, C, mult, chan_stats, Ctot, coff);
   return pdr::check_launch();
 }
@@ -318,7 +490,10 @@ extern "C" int pdr_apply_act(const pdr_layer_in_t* in, long P, int C, float* out
     return PDR_EINVAL;
   if (P == 0) return PDR_OK;
   int ctot = 0;
-  for (int s = 0; s < in->n_seg; ++s) ctot += in->seg[s].C;
+  for (int s = 0; s < in->n_seg; ++s) {
+    if (in->seg[s].row_div < 1 || (in->seg[s].row_div & (in->seg[s].row_div - 1))) return PDR_EUNSUPPORTED;
+    ctot += in->seg[s].C;
+  }
   if (ctot != C) return PDR_EINVAL;
   hipLaunchKernelGGL(apply_act_kernel, dim3(static_cast<unsigned>((P * C + 255) / 256)), dim3(256), 0,
                      pdr::as_stream(stream), *in, P, C, out, ldo);

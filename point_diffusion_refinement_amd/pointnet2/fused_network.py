@@ -94,15 +94,18 @@ def run_layer(act, conv, stats=False, relu_col0=None):
     """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch)."""
     lib = _lib.load()
     assert act.C == conv.Cin, (act.C, conv.Cin)
-    Y = torch.empty((act.P, conv.Cout), dtype=torch.float32, device=conv.Wt.device)
-    tm = lib.pdr_fused_layer_tile_rows(act.rpb)
+    # rows of wide, odd-width outputs (105, 140, 297 ... = [first | res | key] GEMMs) start on
+    # 128-byte boundaries: pad the leading dimension, consumers address columns through `ld`
+    ldy = conv.Cout if (conv.Cout <= 64 or conv.Cout % 32 == 0) else (conv.Cout + 31) // 32 * 32
+    Y = torch.empty((act.P, ldy), dtype=torch.float32, device=conv.Wt.device)
+    tm = lib.pdr_fused_layer_tile_rows(act.rpb, conv.Cout)
     tpb = (act.rpb + tm - 1) // tm
     partial = None
     if stats:
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
-    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.bias.data_ptr(),
-                                   conv.Cout, Y.data_ptr(), conv.Cout,
+    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.Cout,
+                                   conv.bias.data_ptr(), conv.Cout, Y.data_ptr(), ldy,
                                    partial.data_ptr() if stats else None,
                                    conv.Cout if relu_col0 is None else relu_col0, _stream()), "fused_layer")
     return Y, partial, tpb
@@ -236,7 +239,7 @@ class FusedMlp:
         relu0 = self.extra_col0 if relu_stats_extra else None
         Y, part, tpb = run_layer(x, self.first, stats=True, relu_col0=relu0)
         Y1, part1, tpb1 = Y, part, tpb
-        ld = self.first.Cout
+        ld = Y.shape[1]
         cur = Act([(Y, 0, self.C1, ld, 1)], x.P, x.B, x.rpb)
         for i, norm in enumerate(self.norms):
             C = cur.C
@@ -247,7 +250,7 @@ class FusedMlp:
                 cur.add, cur.add_ld = inj[0][:, inj[1]:], inj[2]
             if i < len(self.rest):
                 Y, part, tpb = run_layer(cur, self.rest[i], stats=True)
-                cur = Act([(Y, 0, self.rest[i].Cout, self.rest[i].Cout, 1)], x.P, x.B, x.rpb)
+                cur = Act([(Y, 0, self.rest[i].Cout, Y.shape[1], 1)], x.P, x.B, x.rpb)
         if self.has_res:
             if self.res_col0 is not None:
                 cur.radd = (Y1, self.res_col0, ld)
@@ -288,18 +291,18 @@ class FusedAttention:
         Ct = self.C1 + self.C2
         s, t = self.n1.fold([(qpart, 0, self.C1, qtpb, float(K)), (part1, key_col0, self.C2, tpb1, 1.0)], B, Ct,
                             npoint * K)
-        a = Act([(q, 0, self.C1, self.C1, K), (Y1, key_col0, self.C2, ld1, 1)], P, B, npoint * K, scale=s, shift=t,
-                pre_relu=True)
+        a = Act([(q, 0, self.C1, q.shape[1], K), (Y1, key_col0, self.C2, ld1, 1)], P, B, npoint * K, scale=s,
+                shift=t, pre_relu=True)
         S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
-        scores, _, _ = run_layer(Act([(S1, 0, self.w1.Cout, self.w1.Cout, 1)], P, B, npoint * K, scale=s, shift=t,
+        scores, _, _ = run_layer(Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t,
                                      pre_relu=True), self.w2)
         V, pv, tpv = run_layer(h, self.v, stats=self.v_norm is not None)
         vs = vt = None
         if self.v_norm is not None:
             vs, vt = self.v_norm.fold([(pv, 0, self.D, tpv, 1.0)], B, self.D, npoint * K)
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
-        _lib.check(lib.pdr_attention_pool(scores.data_ptr(), self.D, V.data_ptr(), self.D,
+        _lib.check(lib.pdr_attention_pool(scores.data_ptr(), scores.shape[1], V.data_ptr(), V.shape[1],
                                           vs.data_ptr() if vs is not None else None,
                                           vt.data_ptr() if vt is not None else None, int(self.v_relu),
                                           counts.data_ptr() if counts is not None else None, B, npoint, K, self.D,
@@ -468,9 +471,9 @@ class FusedCloudConditionNet:
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz, 0, 3, 3, 1)], B * N, B, N)
         Y, part, tpb = run_layer(head_in, self.head1, stats=True)
         s, t = self.head_norm.fold([(part, 0, self.head1.Cout, tpb, 1.0)], B, self.head1.Cout, N)
-        out, _, _ = run_layer(Act([(Y, 0, self.head1.Cout, self.head1.Cout, 1)], B * N, B, N, scale=s, shift=t,
+        out, _, _ = run_layer(Act([(Y, 0, self.head1.Cout, Y.shape[1], 1)], B * N, B, N, scale=s, shift=t,
                                   post_relu=True), self.head2)
-        return out.view(B, N, -1)
+        return out[:, :self.head2.Cout].reshape(B, N, -1)
 
     __call__ = forward
 

@@ -1,0 +1,94 @@
+"""Per-launch timing of the fused kernels inside one cached reverse step (HIP events on the launch
+stream), with the algorithmic bytes / flops of every launch.  Diagnostic for kernel work:
+    python tools/layer_times.py [--batch 32]
+"""
+import argparse
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from point_diffusion_refinement_amd.pointnet2 import fused_network as FN  # noqa: E402
+from point_diffusion_refinement_amd.pointnet2.configs import ddpm_pointnet_config, synthetic_batch  # noqa: E402
+from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import \
+    PointNet2CloudCondition  # noqa: E402
+
+
+def instrument(records):
+    """Wrap the kernel entry points of fused_network with event timing + algorithmic traffic."""
+    def wrap(name, fn, meta):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            records.append((name, meta(a, k, out), e0, e1))
+            return out
+        return inner
+
+    def layer_meta(a, k, out):
+        act, conv = a[0], a[1]
+        src_bytes = 0
+        for (t, off, C, ld, div) in act.segs:
+            src_bytes += 4 * C * act.P // div
+        if act.radd is not None:
+            src_bytes += 4 * act.C * act.P
+        return dict(P=act.P, Cin=conv.Cin, Cout=conv.Cout, bytes=src_bytes + 4 * conv.Cout * act.P,
+                    flops=2 * act.P * conv.Cin * conv.Cout)
+
+    FN.run_layer = wrap("fused_layer", FN.run_layer, layer_meta)
+    FN.group_build = wrap("group_build", FN.group_build,
+                          lambda a, k, out: dict(P=out.shape[0], Cin=0, Cout=out.shape[1], bytes=4 * out.numel(),
+                                                 flops=0))
+    FN.materialize = wrap("apply_act", FN.materialize,
+                          lambda a, k, out: dict(P=out.shape[0], Cin=0, Cout=out.shape[1], bytes=8 * out.numel(),
+                                                 flops=0))
+    fold = FN.Norm.fold
+    FN.Norm.fold = wrap("gn_fold", fold, lambda a, k, out: dict(P=0, Cin=0, Cout=out[0].shape[1], bytes=0, flops=0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--top", type=int, default=40)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).to(dev).eval()
+    records = []
+    instrument(records)
+    fused = FN.FusedCloudConditionNet(net)
+    x, cond, label = synthetic_batch(args.batch, seed=0, device=dev)
+    ts = torch.full((args.batch,), 999.0, device=dev)
+    with torch.no_grad():
+        net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        fused.sync_condition()
+        for _ in range(2):
+            fused(x, cond, ts=ts - 1, label=label)
+        records.clear()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fused(x, cond, ts=ts - 2, label=label)
+        e1.record()
+    torch.cuda.synchronize()
+    print("eager fused step: %.2f ms" % e0.elapsed_time(e1))
+    rows = []
+    tot = defaultdict(float)
+    for name, m, a, b in records:
+        ms = a.elapsed_time(b)
+        tot[name] += ms
+        rows.append((ms, name, m))
+    for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+        print("%-12s %7.2f ms  (%d launches)" % (k, v, sum(1 for r in rows if r[1] == k)))
+    print("%-12s %9s %5s %5s %8s %8s %8s" % ("kernel", "P", "Cin", "Cout", "ms", "GB/s", "TFLOP/s"))
+    for ms, name, m in sorted(rows, key=lambda r: -r[0])[:args.top]:
+        print("%-12s %9d %5d %5d %8.3f %8.0f %8.1f" % (name, m["P"], m["Cin"], m["Cout"], ms,
+                                                         m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9))
+
+
+if __name__ == "__main__":
+    main()
