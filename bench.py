@@ -157,7 +157,9 @@ def main():
     if world == 1 and rank == 0:
         try:
             from tools.kernel_roofline import dominant_kernel_roofline
-            out["roofline"] = dominant_kernel_roofline(device, B)
+            if args.unfused:
+                raise RuntimeError("roofline is reported for the fused execution only")
+            out["roofline"] = dominant_kernel_roofline(sampler)
         except Exception as e:  # never lose the headline number to an instrumentation problem
             out["roofline"] = {"error": repr(e)}
         if not args.no_cpu_baseline:

@@ -179,6 +179,9 @@ typedef struct {
 /* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into
  * ceil(rows_per_batch / tile) tiles, the last one possibly partial */
 int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
+/* index of the kernel instantiation used for this shape: 0 256x32, 1 256x64, 2 128x96, 3 128x160,
+ * 4 128x128 (2-D grid), 5 64x128, 6 32x128 */
+int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 /* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight
  * transposed; leading dimension ldw >= Cout), exact fp32 MFMA.  partial: NULL or (B*tiles_per_batch, Cout, 2) floats receiving the
  * per-tile sum / sum of squares of y (columns >= relu_col0: of relu(y)). */

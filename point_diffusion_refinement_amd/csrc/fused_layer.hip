@@ -418,6 +418,13 @@ extern "C" int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout) {
   return pick_tile(rows_per_batch, Cout).tm;
 }
 
+// which kernel instantiation pdr_fused_layer() launches (0..6, see pick_tile); lets profilers and
+// bench.py attribute a launch to its kernel symbol
+extern "C" int pdr_fused_layer_variant(int rows_per_batch, int Cout) {
+  if (rows_per_batch <= 0 || Cout <= 0) return -1;
+  return pick_tile(rows_per_batch, Cout).id;
+}
+
 // Y (P, Cout; leading dim ldy) = prologue(X) . Wt + bias.  partial: NULL or
 // (B * tiles_per_batch, Cout, 2) floats receiving per-tile sum / sum of squares of y
 // (columns >= relu_col0: of relu(y)).

@@ -1,0 +1,93 @@
+"""Batch-sharded test-set generation + evaluation across the GPUs of one node.
+
+This is the arithmetic contract of the reference's generation harness -- not its CLI / file
+plumbing -- for one process per GPU:
+
+  * shard split      mvp_dataloader/mvp_dataset.py:152-198 : GT shapes are split evenly,
+                     per = ceil(G / W); rank r owns shapes [r*per, (r+1)*per) and their 26 partial
+                     views [r*per*26, (r+1)*per*26)  (the last rank may be short: generation uses
+                     append_samples_to_last_rank=False, generate_samples.py:191-192)
+  * per batch        completion_eval.py:145-265 : reset condition cache, T-step reverse sampling,
+                     x/2/scale and gt/2/scale, Chamfer (cd_t, cd_p, F1 at 1e-4) and EMD per sample
+  * gather           generate_samples_distributed.py:26-97 : per-rank results concatenated IN RANK
+                     ORDER, then plain means.  The reference does this through .pkl/.h5 files; here
+                     it is ONE all_gather of (n_local, 5) float32 records
+                     [cd_t, cd_p, f1, emd, label] over RCCL (backend "nccl"; "gloo" in CPU tests).
+                     No collective runs inside the sampling loop; generated clouds stay rank-local.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+VIEWS_PER_SHAPE = 26   # mvp_dataset.py:150,289: 26 partial views per complete shape
+
+
+def rank_shard(num_shapes, rank, world_size, views=VIEWS_PER_SHAPE):
+    """(first_partial, last_partial_exclusive, first_shape, last_shape_exclusive) owned by `rank`."""
+    per = int(math.ceil(num_shapes / world_size)) if world_size > 1 else num_shapes
+    start, end = rank * per, min((rank + 1) * per, num_shapes)
+    start = min(start, num_shapes)
+    return start * views, end * views, start, end
+
+
+def batches(first, last, batch_size):
+    """Consecutive [lo, hi) index ranges of a shard, the last one possibly short (no drop_last)."""
+    return [(lo, min(lo + batch_size, last)) for lo in range(first, last, batch_size)]
+
+
+def evaluate_batch(generate, condition, label, gt, scale=1.0, f1_threshold=1e-4, compute_emd=True):
+    """One batch of the harness: `generate(condition, label)` -> (B,N,3) completed clouds.
+    Returns (generated/2/scale, records (B,5) = [cd_t, cd_p, f1, emd, label])."""
+    from .chamfer_loss_new import calc_cd
+    from .emd import earth_mover_distance
+    generated = generate(condition, label)
+    generated = generated / 2 / scale
+    gt = gt / 2 / scale
+    cd_p, cd_t, f1 = calc_cd(generated, gt, calc_f1=True, f1_threshold=f1_threshold)
+    emd = earth_mover_distance(generated, gt) if compute_emd else torch.zeros_like(cd_t)
+    rec = torch.stack([cd_t, cd_p, f1, emd, label.to(cd_t.dtype)], dim=1)
+    return generated, rec
+
+
+def gather_records(records, group=None):
+    """All ranks' (n_r, C) records concatenated in rank order -> (sum n_r, C) on every rank.
+    Shards may have different lengths (last rank short): lengths are exchanged first and the
+    payload is padded to the longest shard -- two tiny collectives for the whole job."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return records
+    world = dist.get_world_size(group)
+    n = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = records.shape[1]
+    padded = torch.zeros((max(counts), width), dtype=records.dtype, device=records.device)
+    padded[:records.shape[0]] = records
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def summarize(all_records):
+    """Means exactly as generate_samples_distributed.py:84-95 computes them (concatenate, .mean())."""
+    cd_t, cd_p, f1, emd = (all_records[:, i] for i in range(4))
+    return {"avg_cd": float(cd_t.mean()), "avg_cd_p": float(cd_p.mean()), "avg_f1": float(f1.mean()),
+            "avg_emd": float(emd.mean()), "num_samples": int(all_records.shape[0])}
+
+
+def generate_and_evaluate(generate, dataset, num_shapes, batch_size, rank=0, world_size=1, scale=1.0,
+                          compute_emd=True, group=None):
+    """Run this rank's shard.  `dataset(lo, hi)` -> (condition, label, gt) for partial indices [lo, hi)
+    (gt already expanded per partial view: gt_idx = index // 26, mvp_dataset.py:289).
+    Returns (local generated clouds, ALL ranks' records in rank order, summary)."""
+    first, last, _, _ = rank_shard(num_shapes, rank, world_size)
+    clouds, recs = [], []
+    for lo, hi in batches(first, last, batch_size):
+        condition, label, gt = dataset(lo, hi)
+        g, r = evaluate_batch(generate, condition, label, gt, scale=scale, compute_emd=compute_emd)
+        clouds.append(g)
+        recs.append(r)
+    local = torch.cat(recs, 0) if recs else torch.zeros((0, 5))
+    everything = gather_records(local, group=group)
+    return (torch.cat(clouds, 0) if clouds else None), everything, summarize(everything)
