@@ -183,7 +183,9 @@ int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
  * 4 128x128 (2-D grid), 5 64x128, 6 32x128 */
 int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 /* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight
- * transposed; leading dimension ldw >= Cout), exact fp32 MFMA.  partial: NULL or (B*tiles_per_batch, Cout, 2) floats receiving the
+ * transposed; 16-B aligned, leading dimension ldw >= Cout with ldw % 4 == 0), exact fp32 MFMA.
+ * Sources whose pointers are 16-B aligned and whose leading dimensions are multiples of 4 floats
+ * (rows padded to a multiple of 4 channels) are staged with 16-B loads.  partial: NULL or (B*tiles_per_batch, Cout, 2) floats receiving the
  * per-tile sum / sum of squares of y (columns >= relu_col0: of relu(y)). */
 int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,
@@ -192,6 +194,11 @@ int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, 
  * `partial` points at the first of C columns inside rows of ldp columns */
 int pdr_gn_reduce(const float *partial, int ldp, int B, int tiles_per_batch, int C, double mult,
                   double *chan_stats, int Ctot, int coff, pdr_stream_t stream);
+/* pdr_gn_reduce (x1 or x2 sources) + pdr_gn_finalize in one launch; part1 may be NULL */
+int pdr_gn_fold(const float *part0, int ldp0, int tpb0, int C0, double mult0, const float *part1,
+                int ldp1, int tpb1, int C1, double mult1, int B, int Cn, int G, double n, float eps,
+                const float *gamma, const float *beta, float *scale, float *shift,
+                pdr_stream_t stream);
 /* out (P,C; ld ldo) = prologue(X): materialise an activation descriptor */
 int pdr_apply_act(const pdr_layer_in_t *in, long P, int C, float *out, int ldo,
                   pdr_stream_t stream);
@@ -200,15 +207,16 @@ int pdr_apply_act(const pdr_layer_in_t *in, long P, int C, float *out, int ldo,
 int pdr_gn_finalize(const double *chan_stats, int B, int C, int Cn, int G, double n, float eps,
                     const float *gamma, const float *beta, float *scale, float *shift,
                     pdr_stream_t stream);
-/* out (B,m,K, Cs+3[+3][+3]) = [feats[idx] | rel | abs | centre]; feats (B,n,Cs) channel-last */
+/* out (B*m*K rows of leading dimension ldo >= Cs+3[+3][+3]) = [feats[idx] | rel | abs | centre];
+ * feats (B,n,Cs) channel-last; columns beyond the row width are zero-filled */
 int pdr_group_build(const float *feats, int Cs, const float *xyz, const float *new_xyz,
                     const int *idx, const int *counts, int B, int n, int m, int K,
-                    int patch_empty, int with_abs, int with_centre, float *out,
+                    int patch_empty, int with_abs, int with_centre, float *out, int ldo,
                     pdr_stream_t stream);
-/* out (B,n1,K, C+11) = [feats_y[idx] | d2 | w | nn_abs | nn_rel | x]; idx int64 (B,n1,K) */
+/* out (B*n1*K rows, ld ldo >= C+11) = [feats_y[idx] | d2 | w | nn_abs | nn_rel | x]; idx int64 (B,n1,K) */
 int pdr_knn_build(const float *feats_y, int C, const float *x, const float *y,
                   const long long *idx, const float *d2, int B, int n1, int n2, int K,
-                  float *out, pdr_stream_t stream);
+                  float *out, int ldo, pdr_stream_t stream);
 /* out (B*npoint, D) = sum_k softmax_k(mask(scores)) * act(values*vscale+vshift);
  * scores/values (B*npoint*K, D) with leading dims lds/ldv; counts (B,npoint) or NULL = 'all' */
 int pdr_attention_pool(const float *scores, int lds, const float *values, int ldv,

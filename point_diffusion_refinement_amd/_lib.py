@@ -43,9 +43,11 @@ SIGNATURES = {
     "pdr_fused_layer": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pdr_gn_reduce": (_I, [_P, _I, _I, _I, _I, _c.c_double, _P, _I, _I, _P]),
     "pdr_apply_act": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
+    "pdr_gn_fold": (_I, [_P, _I, _I, _I, _c.c_double, _P, _I, _I, _I, _c.c_double, _I, _I, _I, _c.c_double, _F,
+                         _P, _P, _P, _P, _P]),
     "pdr_gn_finalize": (_I, [_P, _I, _I, _I, _I, _c.c_double, _F, _P, _P, _P, _P, _P]),
-    "pdr_group_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "pdr_knn_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_group_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "pdr_knn_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_attention_pool": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
 }

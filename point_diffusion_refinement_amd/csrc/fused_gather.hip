@@ -17,64 +17,78 @@
 
 namespace {
 
-// one thread per output element e = p * Cout + c
+// LPP lanes per position p = (b, j, k) (16 / 32 / 64 by row width); the lanes of a group stride over
+// the output channels, so the neighbour's feature row is read as one contiguous segment and the
+// output row is written contiguously; index / count are loaded once per group.
+template <int LPP>
 __global__ __launch_bounds__(256) void group_build_kernel(
     const float* __restrict__ feats, int Cs, int n, const float* __restrict__ xyz,
     const float* __restrict__ new_xyz, const int* __restrict__ idx, const int* __restrict__ counts,
-    int m, int K, int patch_empty, int with_abs, int with_centre, long total, int Cout,
+    int m, int K, int patch_empty, int with_abs, int with_centre, long npos, int Cout, int ldo,
     float* __restrict__ out) {
-  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= total) return;
-  const long p = e / Cout;
-  const int c = static_cast<int>(e - p * Cout);
-  const long bj = p / K;                 // b * m + j
-  const int b = static_cast<int>(bj / m);
-  const int a = idx[p];
-  const bool empty = patch_empty && counts[bj] <= 0;
-  float v;
-  if (c < Cs) {
-    v = empty ? 0.0f : feats[(static_cast<long>(b) * n + a) * Cs + c];
-  } else {
-    const int g = c - Cs;                // 0..2 rel, 3..5 abs, then centre
-    const int d = g % 3;
-    const float ctr = new_xyz[bj * 3 + d];
-    const float ab = empty ? ctr : xyz[(static_cast<long>(b) * n + a) * 3 + d];
-    const int kind = g / 3;              // 0 rel, 1 abs|centre, 2 centre
-    if (kind == 0) v = ab - ctr;
-    else if (kind == 1) v = with_abs ? ab : ctr;
-    else v = ctr;
+  constexpr int GPB = 256 / LPP;           // position groups per workgroup
+  const int lane = threadIdx.x % LPP;
+  const long g0 = static_cast<long>(blockIdx.x) * GPB + threadIdx.x / LPP;
+  const long ngroups = static_cast<long>(gridDim.x) * GPB;
+  for (long p = g0; p < npos; p += ngroups) {
+    const long bj = p / K;                 // b * m + j
+    const int b = static_cast<int>(bj / m);
+    const int a = idx[p];
+    const bool empty = patch_empty && counts[bj] <= 0;
+    const float* frow = feats + (static_cast<long>(b) * n + a) * Cs;
+    float* orow = out + p * ldo;
+    for (int c = lane; c < Cs; c += LPP) orow[c] = empty ? 0.0f : frow[c];
+    if (lane < ldo - Cout) orow[Cout + lane] = 0.0f;   // padding columns
+    if (lane < Cout - Cs) {
+      const int g = lane;                  // 0..2 rel, 3..5 abs|centre, 6..8 centre
+      const int d = g % 3;
+      const float ctr = new_xyz[bj * 3 + d];
+      const float ab = empty ? ctr : xyz[(static_cast<long>(b) * n + a) * 3 + d];
+      const int kind = g / 3;
+      float v;
+      if (kind == 0) v = ab - ctr;
+      else if (kind == 1) v = with_abs ? ab : ctr;
+      else v = ctr;
+      orow[Cs + g] = v;
+    }
   }
-  out[e] = v;
 }
 
+template <int LPP>
 __global__ __launch_bounds__(256) void knn_build_kernel(
     const float* __restrict__ feats_y, int C, int n2, const float* __restrict__ x,
     const float* __restrict__ y, const long long* __restrict__ idx, const float* __restrict__ d2,
-    int n1, int K, long total, int Cout, float* __restrict__ out) {
-  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= total) return;
-  const long p = e / Cout;               // (b, i, k)
-  const int c = static_cast<int>(e - p * Cout);
-  const long bi = p / K;
-  const int b = static_cast<int>(bi / n1);
-  const long a = idx[p];
-  float v;
-  if (c < C) {
-    v = feats_y[(static_cast<long>(b) * n2 + a) * C + c];
-  } else if (c == C) {
-    v = d2[p];
-  } else if (c == C + 1) {
-    float norm = 0.0f;
-    for (int k = 0; k < K; ++k) norm += 1.0f / (d2[bi * K + k] + 1e-8f);
-    v = (1.0f / (d2[p] + 1e-8f)) / norm;
-  } else {
-    const int g = c - C - 2;             // 0..2 nn_abs, 3..5 nn_rel, 6..8 x
-    const int d = g % 3;
-    const float xq = x[bi * 3 + d];
-    const float ab = y[(static_cast<long>(b) * n2 + a) * 3 + d];
-    v = g < 3 ? ab : (g < 6 ? ab - xq : xq);
+    int n1, int K, long npos, int Cout, int ldo, float* __restrict__ out) {
+  constexpr int GPB = 256 / LPP;
+  const int lane = threadIdx.x % LPP;
+  const long g0 = static_cast<long>(blockIdx.x) * GPB + threadIdx.x / LPP;
+  const long ngroups = static_cast<long>(gridDim.x) * GPB;
+  for (long p = g0; p < npos; p += ngroups) {
+    const long bi = p / K;                 // (b, i)
+    const int b = static_cast<int>(bi / n1);
+    const long a = idx[p];
+    const float* frow = feats_y + (static_cast<long>(b) * n2 + a) * C;
+    float* orow = out + p * ldo;
+    for (int c = lane; c < C; c += LPP) orow[c] = frow[c];
+    if (lane >= 11 && lane < 11 + ldo - Cout) orow[Cout + lane - 11] = 0.0f;   // padding columns
+    if (lane < 11) {
+      float v;
+      if (lane == 0) {
+        v = d2[p];
+      } else if (lane == 1) {
+        float norm = 0.0f;
+        for (int k = 0; k < K; ++k) norm += 1.0f / (d2[bi * K + k] + 1e-8f);
+        v = (1.0f / (d2[p] + 1e-8f)) / norm;
+      } else {
+        const int g = lane - 2;            // 0..2 nn_abs, 3..5 nn_rel, 6..8 x
+        const int d = g % 3;
+        const float xq = x[bi * 3 + d];
+        const float ab = y[(static_cast<long>(b) * n2 + a) * 3 + d];
+        v = g < 3 ? ab : (g < 6 ? ab - xq : xq);
+      }
+      orow[C + lane] = v;
+    }
   }
-  out[e] = v;
 }
 
 // thread per (row = b*npoint + j, d); lanes run over d -> coalesced reads of scores/values
@@ -132,32 +146,52 @@ inline unsigned blocks_for(long total) { return static_cast<unsigned>((total + 2
 
 extern "C" int pdr_group_build(const float* feats, int Cs, const float* xyz, const float* new_xyz,
                                const int* idx, const int* counts, int B, int n, int m, int K,
-                               int patch_empty, int with_abs, int with_centre, float* out,
+                               int patch_empty, int with_abs, int with_centre, float* out, int ldo,
                                pdr_stream_t stream) {
   if (B < 0 || n <= 0 || m < 0 || K <= 0 || Cs < 0) return PDR_EINVAL;
   if (B == 0 || m == 0) return PDR_OK;
   if (!xyz || !new_xyz || !idx || !out || (Cs > 0 && !feats) || (patch_empty && !counts))
     return PDR_EINVAL;
   const int Cout = Cs + 3 + (with_abs ? 3 : 0) + (with_centre ? 3 : 0);
-  const long total = static_cast<long>(B) * m * K * Cout;
+  if (ldo < Cout || ldo - Cout > 8) return PDR_EINVAL;
+  const long npos = static_cast<long>(B) * m * K;
   // channel order after the features: rel | (abs) | (centre); the kernel's `kind` 1 slot is abs
   // when with_abs else centre
-  hipLaunchKernelGGL(group_build_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream),
-                     feats, Cs, n, xyz, new_xyz, idx, counts, m, K, patch_empty, with_abs, with_centre,
-                     total, Cout, out);
+  hipStream_t s = pdr::as_stream(stream);
+#define PDR_GB(LPP)                                                                                 \
+  do {                                                                                              \
+    const long nblk = (npos + 256 / LPP - 1) / (256 / LPP);                                         \
+    hipLaunchKernelGGL(group_build_kernel<LPP>, dim3(static_cast<unsigned>(nblk < 32768 ? nblk : 32768)), \
+                       dim3(256), 0, s, feats, Cs, n, xyz, new_xyz, idx, counts, m, K, patch_empty, \
+                       with_abs, with_centre, npos, Cout, ldo, out);                                \
+  } while (0)
+  if (Cout <= 16) PDR_GB(16);
+  else if (Cout <= 48) PDR_GB(32);
+  else PDR_GB(64);
+#undef PDR_GB
   return pdr::check_launch();
 }
 
 extern "C" int pdr_knn_build(const float* feats_y, int C, const float* x, const float* y,
                              const long long* idx, const float* d2, int B, int n1, int n2, int K,
-                             float* out, pdr_stream_t stream) {
+                             float* out, int ldo, pdr_stream_t stream) {
   if (B < 0 || n1 < 0 || n2 <= 0 || K <= 0 || C < 0) return PDR_EINVAL;
   if (B == 0 || n1 == 0) return PDR_OK;
   if (!x || !y || !idx || !d2 || !out || (C > 0 && !feats_y)) return PDR_EINVAL;
   const int Cout = C + 11;
-  const long total = static_cast<long>(B) * n1 * K * Cout;
-  hipLaunchKernelGGL(knn_build_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream),
-                     feats_y, C, n2, x, y, idx, d2, n1, K, total, Cout, out);
+  if (ldo < Cout || ldo - Cout > 8) return PDR_EINVAL;
+  const long npos = static_cast<long>(B) * n1 * K;
+  hipStream_t s = pdr::as_stream(stream);
+#define PDR_KB(LPP)                                                                                 \
+  do {                                                                                              \
+    const long nblk = (npos + 256 / LPP - 1) / (256 / LPP);                                         \
+    hipLaunchKernelGGL(knn_build_kernel<LPP>, dim3(static_cast<unsigned>(nblk < 32768 ? nblk : 32768)), \
+                       dim3(256), 0, s, feats_y, C, n2, x, y, idx, d2, n1, K, npos, Cout, ldo, out); \
+  } while (0)
+  if (Cout <= 16) PDR_KB(16);
+  else if (Cout <= 48) PDR_KB(32);
+  else PDR_KB(64);
+#undef PDR_KB
   return pdr::check_launch();
 }
 

@@ -75,18 +75,26 @@ __device__ __forceinline__ float load_col(const ColSrc& s, long row) {
 // load is `scalar base + 32-bit lane offset`.
 // Pipeline per chunk: global -> registers (prologue applied) is issued BEFORE the MFMAs of the
 // previous chunk, registers -> LDS after them: the loads overlap the matrix pipe.
-template <int RT, int CT, int WR, int WC, int KC, bool RADD>
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC>
 __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
     float* __restrict__ partial, int relu_col0, int n_row_tiles) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
-  constexpr int APT = TM * KC / 256;   // A elements per thread per chunk
-  constexpr int WPT = (KC * TN + 255) / 256;   // W elements per thread per chunk
-  constexpr int RSTEP = 256 / KC;      // row stride between a thread's A elements
+  // scalar A path: thread -> (column ac, rows ar0 + RSTEP i)
+  constexpr int APT = TM * KC / 256;
+  constexpr int RSTEP = 256 / KC;
+  // vector A path (VEC: every segment 16-B aligned, ld % 4 == 0): thread -> (float4 column vc4,
+  // rows vr0 + VSTEP i): 4x fewer load instructions and address computations
+  constexpr int C4 = KC / 4;
+  constexpr int VSTEP = 256 / C4;
+  constexpr int APT4 = TM / VSTEP;
+  // W chunk (always float4; Wt is packed with ldw % 4 == 0): element e4 = tid + 256 i
+  constexpr int TN4 = TN / 4;
+  constexpr int WPT4 = (KC * TN4 + 255) / 256;
   __shared__ float As[KC][TM + 1];
-  __shared__ float Bs[KC][TN + 1];
+  __shared__ __attribute__((aligned(16))) float Bs[KC][TN + 4];
   __shared__ float red[WR][TN][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,8 +103,6 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
   const int rpb = in.rows_per_batch;
   const int tpb = (rpb + TM - 1) / TM;
   const int n0 = blockIdx.y * TN;
-  const int ac_ = tid % KC, ar0_ = tid / KC;        // this thread's A column-in-chunk / first row
-  // W chunk element e = tid + 256 i  ->  (row e / TN, column e % TN); TN need not divide 256
   const float lo_pre = in.pre_relu ? 0.0f : -__builtin_inff();
   const float lo_post = in.post_relu ? 0.0f : -__builtin_inff();
   const bool single_chunk = in.n_seg == 1 && Cin <= KC;   // W staged once per workgroup
@@ -108,9 +114,13 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     const int col = n0 + (wc * CT + j) * 32 + il;
     bias_r[j] = (bias && col < Cout) ? bias[col] : 0.0f;
   }
-  float ra[APT], rw[WPT];
-  float rr[RADD ? APT : 1];
-  float f_s = 1.0f, f_h = 0.0f, f_a = 0.0f;   // prologue parameters of the chunk in flight
+  // registers of the chunk in flight
+  float ra[VEC ? 1 : APT], rr[(RADD && !VEC) ? APT : 1];
+  float4 rv[VEC ? APT4 : 1], rrv[(RADD && VEC) ? APT4 : 1];
+  float4 rwv[WPT4];
+  float ps[VEC ? 4 : 1], ph[VEC ? 4 : 1], pa[VEC ? 4 : 1];   // per-channel prologue parameters
+  float pok[(VEC && RADD) ? 4 : 1];                           // 1 / 0: channel inside the segment
+  float f_s = 1.0f, f_h = 0.0f, f_a = 0.0f;
   bool f_cok = false;
   int f_kmax = 0;
 
@@ -129,64 +139,121 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     // (sg, ks, cbase): segment, channel offset inside it, global channel index of its first channel
     auto fetch = [&](int sg, int ks, int cbase) {
       // `opaque`: re-materialise the per-thread indices on every call.  Without it LLVM hoists the
-      // 2 x (APT + WPT) loop-invariant row / address values out of the chunk loop and keeps them
-      // alive across the MFMA loop (>100 VGPRs, occupancy 1).
-      int ar0 = ar0_, ac = ac_, wt = tid;
-      asm volatile("" : "+v"(ar0), "+v"(ac), "+v"(wt));
+      // loop-invariant row / address values out of the chunk loop and keeps them alive across the
+      // MFMA loop (>100 VGPRs, occupancy 1).
+      int t = tid;
+      asm volatile("" : "+v"(t));
       const pdr_seg_t seg = in.seg[sg];
       const int shift = __builtin_ctz(seg.row_div);
       const float* abase = seg.ptr + (row0 >> shift) * seg.ld;      // uniform; row0 % row_div == 0
-      const int cl = ks + ac;                                        // channel inside the segment
-      f_cok = cl < seg.C;
-      const int cc = f_cok ? cl : seg.C - 1;
-      const int cg = cbase + cc;                                     // global input channel
-      // channels beyond the segment read a valid address and are forced to 0 in commit()
-      f_s = sc_b ? sc_b[cg] : 1.0f;
-      f_h = sh_b ? sh_b[cg] : 0.0f;
-      f_a = ad_b ? ad_b[cg] : 0.0f;
+      f_kmax = min(KC, seg.C - ks);                                  // valid channels in this chunk
+      if constexpr (VEC) {
+        const int vc4 = t % C4, vr0 = t / C4;
+        const int cl = ks + 4 * vc4;                                 // first channel of this float4
+        const int clc = min(cl, ((seg.C + 3) & ~3) - 4);             // keep the 16-B load in the row
+        f_cok = cl == clc;                                           // else: all 4 lanes are padding
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        // rows beyond nvalid re-read the tile's last row; their results are masked in the epilogue
-        const int r = min(ar0 + RSTEP * i, nvalid - 1);
-        ra[i] = abase[(r >> shift) * seg.ld + cc];
-      }
-      if constexpr (RADD) {
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = f_cok && (clc + j) < seg.C;
+          const int cg = cbase + min(clc + j, seg.C - 1);
+          // channels beyond the segment are forced to 0 (scale = shift = add = 0)
+          ps[j] = ok ? (sc_b ? sc_b[cg] : 1.0f) : 0.0f;
+          ph[j] = (ok && sh_b) ? sh_b[cg] : 0.0f;
+          pa[j] = (ok && ad_b) ? ad_b[cg] : 0.0f;
+          if constexpr (RADD) pok[j] = ok ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < APT4; ++i) {
+          // rows beyond nvalid re-read the tile's last row; masked in the epilogue
+          const int r = min(vr0 + VSTEP * i, nvalid - 1);
+          rv[i] = *reinterpret_cast<const float4*>(abase + (r >> shift) * seg.ld + clc);
+        }
+        if constexpr (RADD) {
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) {
+            const int r = min(vr0 + VSTEP * i, nvalid - 1);
+            rrv[i] = *reinterpret_cast<const float4*>(rd_b + r * in.radd_ld + cbase + clc);
+          }
+        }
+      } else {
+        const int ac = t % KC, ar0 = t / KC;
+        const int cl = ks + ac;                                      // channel inside the segment
+        f_cok = cl < seg.C;
+        const int cc = f_cok ? cl : seg.C - 1;
+        const int cg = cbase + cc;                                   // global input channel
+        f_s = sc_b ? sc_b[cg] : 1.0f;
+        f_h = sh_b ? sh_b[cg] : 0.0f;
+        f_a = ad_b ? ad_b[cg] : 0.0f;
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
           const int r = min(ar0 + RSTEP * i, nvalid - 1);
-          rr[i] = rd_b[r * in.radd_ld + cg];
+          ra[i] = abase[(r >> shift) * seg.ld + cc];
+        }
+        if constexpr (RADD) {
+#pragma unroll
+          for (int i = 0; i < APT; ++i) {
+            const int r = min(ar0 + RSTEP * i, nvalid - 1);
+            rr[i] = rd_b[r * in.radd_ld + cg];
+          }
         }
       }
-      f_kmax = min(KC, seg.C - ks);                                  // valid W rows in this chunk
       if (!(single_chunk && w_loaded)) {
         const float* wbase = Wt + static_cast<long>(cbase + ks) * ldw + n0;
+        const int nmax = ldw - n0 - 4;                               // last in-row float4 offset
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-          const int e = wt + 256 * i;
-          const int k = e / TN, n = e - k * TN;
-          rw[i] = wbase[min(k, f_kmax - 1) * ldw + min(n, Cout - 1 - n0)];
+        for (int i = 0; i < WPT4; ++i) {
+          const int e = t + 256 * i;
+          const int k = e / TN4, n4 = e - k * TN4;
+          rwv[i] = *reinterpret_cast<const float4*>(wbase + min(k, f_kmax - 1) * ldw + min(4 * n4, nmax));
         }
       }
     };
     auto commit = [&]() {
-      int ar0 = ar0_, ac = ac_, wt = tid;
-      asm volatile("" : "+v"(ar0), "+v"(ac), "+v"(wt));
-      const float s = f_cok ? f_s : 0.0f, h = f_cok ? f_h : 0.0f, a = f_cok ? f_a : 0.0f;
-      const float rok = f_cok ? 1.0f : 0.0f;
+      int t = tid;
+      asm volatile("" : "+v"(t));
+      if constexpr (VEC) {
+        const int vc4 = t % C4, vr0 = t / C4;
 #pragma unroll
-      for (int i = 0; i < APT; ++i) {
-        float v = fmaxf(ra[i], lo_pre);
-        v = __builtin_fmaf(v, s, h);
-        v = fmaxf(v, lo_post) + a;
-        if constexpr (RADD) v = __builtin_fmaf(rr[i], rok, v);
-        As[ac][ar0 + RSTEP * i] = v;
+        for (int i = 0; i < APT4; ++i) {
+          const float x[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+          float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if constexpr (RADD) {
+            q[0] = rrv[i].x; q[1] = rrv[i].y; q[2] = rrv[i].z; q[3] = rrv[i].w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = fmaxf(x[j], lo_pre);
+            v = __builtin_fmaf(v, ps[j], ph[j]);
+            v = fmaxf(v, lo_post) + pa[j];
+            if constexpr (RADD) v = __builtin_fmaf(q[j], pok[j], v);
+            As[4 * vc4 + j][vr0 + VSTEP * i] = v;
+          }
+        }
+      } else {
+        const int ac = t % KC, ar0 = t / KC;
+        const float s = f_cok ? f_s : 0.0f, h = f_cok ? f_h : 0.0f, a = f_cok ? f_a : 0.0f;
+        const float rok = f_cok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+          float v = fmaxf(ra[i], lo_pre);
+          v = __builtin_fmaf(v, s, h);
+          v = fmaxf(v, lo_post) + a;
+          if constexpr (RADD) v = __builtin_fmaf(rr[i], rok, v);
+          As[ac][ar0 + RSTEP * i] = v;
+        }
       }
       if (!(single_chunk && w_loaded)) {
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-          const int e = wt + 256 * i;
-          const int k = e / TN, n = e - k * TN;
-          if (e < KC * TN) Bs[k][n] = (k < f_kmax && n0 + n < Cout) ? rw[i] : 0.0f;
+        for (int i = 0; i < WPT4; ++i) {
+          const int e = t + 256 * i;
+          const int k = e / TN4, n4 = e - k * TN4;
+          const bool kok = k < f_kmax;
+          float4 w = rwv[i];
+          w.x = (kok && n0 + 4 * n4 + 0 < Cout) ? w.x : 0.0f;
+          w.y = (kok && n0 + 4 * n4 + 1 < Cout) ? w.y : 0.0f;
+          w.z = (kok && n0 + 4 * n4 + 2 < Cout) ? w.z : 0.0f;
+          w.w = (kok && n0 + 4 * n4 + 3 < Cout) ? w.w : 0.0f;
+          if (e < KC * TN4) *reinterpret_cast<float4*>(&Bs[k][4 * n4]) = w;
         }
         w_loaded = true;
       }
@@ -340,6 +407,79 @@ __global__ __launch_bounds__(1024) void gn_reduce_kernel(const float* __restrict
   }
 }
 
+// gn_reduce + gn_finalize for up to two partial sources in ONE launch: block b reduces the tile
+// partials of batch element b into LDS (double), then folds GroupNorm to scale / shift.
+struct FoldPart {
+  const float* partial;   // first of `C` columns inside rows of `ldp` columns
+  int ldp, tiles_per_batch, C;
+  double mult;
+};
+
+__global__ __launch_bounds__(1024) void gn_fold_kernel(FoldPart p0, FoldPart p1, int C, int Cn, int G,
+                                                       double n, float eps,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       float* __restrict__ scale,
+                                                       float* __restrict__ shift) {
+  extern __shared__ __attribute__((aligned(16))) double cs[];   // [C][2]
+  __shared__ double red[32][32][2];
+  const int b = blockIdx.x;
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  int coff = 0;
+  for (int part = 0; part < 2; ++part) {
+    const FoldPart p = part == 0 ? p0 : p1;
+    if (!p.partial) continue;
+    for (int c0 = 0; c0 < p.C; c0 += 32) {
+      const int c = c0 + cl;
+      double s1 = 0.0, s2 = 0.0;
+      if (c < p.C) {
+        const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + c) * 2;
+        for (int t = sl; t < p.tiles_per_batch; t += 32) {
+          const float2 v = *reinterpret_cast<const float2*>(q + static_cast<long>(t) * p.ldp * 2);
+          s1 += v.x;
+          s2 += v.y;
+        }
+      }
+      red[sl][cl][0] = s1;
+      red[sl][cl][1] = s2;
+      __syncthreads();
+      if (sl == 0 && c < p.C) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+          a1 += red[k][cl][0];
+          a2 += red[k][cl][1];
+        }
+        cs[(coff + c) * 2 + 0] = a1 * p.mult;
+        cs[(coff + c) * 2 + 1] = a2 * p.mult;
+      }
+      __syncthreads();
+    }
+    coff += p.C;
+  }
+  for (int c = threadIdx.x; c < C; c += 1024) {
+    float sc = 1.0f, sh = 0.0f;
+    if (c < Cn) {
+      const int cpg = Cn / G;
+      const int g0 = (c / cpg) * cpg;
+      double s1 = 0.0, s2 = 0.0;
+      for (int j = 0; j < cpg; ++j) {
+        s1 += cs[(g0 + j) * 2 + 0];
+        s2 += cs[(g0 + j) * 2 + 1];
+      }
+      const double cnt = n * cpg;
+      const double mean = s1 / cnt;
+      double var = s2 / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+      sc = rstd * gamma[c];
+      sh = __builtin_fmaf(-sc, static_cast<float>(mean), beta[c]);
+    }
+    scale[static_cast<long>(b) * C + c] = sc;
+    shift[static_cast<long>(b) * C + c] = sh;
+  }
+}
+
 // out (P, C; ld ldo) = prologue(X): materialise an activation (needed where the next consumer
 // gathers whole feature rows, e.g. group_build / gather_rows)
 __global__ __launch_bounds__(256) void apply_act_kernel(pdr_layer_in_t in, long P, int C,
@@ -434,6 +574,8 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   if (!in || !Wt || !Y || P < 0 || Cin <= 0 || Cout <= 0 || in->n_seg < 1 || in->n_seg > 4 ||
       ldw < Cout || ldy < Cout)
     return PDR_EINVAL;
+  // the weight matrix is staged with 16-B loads: packed with a 4-float-aligned leading dimension
+  if (ldw % 4 != 0 || reinterpret_cast<uintptr_t>(Wt) % 16 != 0) return PDR_EINVAL;
   if (P == 0) return PDR_OK;
   int ctot = 0;
   for (int s = 0; s < in->n_seg; ++s) {
@@ -458,14 +600,28 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
   const int nt = static_cast<int>(ntiles);
-#define PDR_LAUNCH(RT, CT, WR, WC, KC)                                                              \
-  do {                                                                                               \
-    if (in->radd)                                                                                    \
-      hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, true>), grid, dim3(256), 0, s, *in, \
-                         Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);                  \
-    else                                                                                             \
-      hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false>), grid, dim3(256), 0, s,     \
-                         *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);             \
+  // vector (float4) A staging needs every source 16-B aligned with a leading dimension that is a
+  // multiple of 4 floats and rows padded to a multiple of 4 channels
+  bool vec = true;
+  for (int sg = 0; sg < in->n_seg; ++sg) {
+    const pdr_seg_t& g = in->seg[sg];
+    vec = vec && (reinterpret_cast<uintptr_t>(g.ptr) % 16 == 0) && g.ld % 4 == 0 && g.ld >= ((g.C + 3) & ~3);
+  }
+  if (in->radd)
+    vec = vec && in->n_seg == 1 && (reinterpret_cast<uintptr_t>(in->radd) % 16 == 0) && in->radd_ld % 4 == 0 &&
+          in->radd_ld >= ((Cin + 3) & ~3);
+#define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC)                                               \
+  hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC>), grid, dim3(256), 0, s, *in, \
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt)
+#define PDR_LAUNCH(RT, CT, WR, WC, KC)                          \
+  do {                                                          \
+    if (in->radd) {                                             \
+      if (vec) PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, true);    \
+      else PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, false);       \
+    } else {                                                    \
+      if (vec) PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, true);   \
+      else PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, false);      \
+    }                                                           \
   } while (0)
   switch (t.id) {
     case 0: PDR_LAUNCH(2, 1, 4, 1, 16); break;
@@ -477,6 +633,7 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     default: PDR_LAUNCH(1, 1, 1, 4, 32); break;
   }
 #undef PDR_LAUNCH
+#undef PDR_LAUNCH_V
   return pdr::check_launch();
 }
 
@@ -488,6 +645,25 @@ extern "C" int pdr_gn_reduce(const float* partial, int ldp, int B, int tiles_per
     return PDR_EINVAL;
   hipLaunchKernelGGL(gn_reduce_kernel, dim3((C + 31) / 32, B), dim3(1024), 0, pdr::as_stream(stream),
                      partial, ldp, tiles_per_batch, C, mult, chan_stats, Ctot, coff);
+  return pdr::check_launch();
+}
+
+// One-launch GroupNorm fold: up to two partial sources (second may be NULL) covering C = C0 + C1
+// channels in order; see pdr_gn_reduce / pdr_gn_finalize for the semantics.
+extern "C" int pdr_gn_fold(const float* part0, int ldp0, int tpb0, int C0, double mult0,
+                           const float* part1, int ldp1, int tpb1, int C1, double mult1, int B, int Cn,
+                           int G, double n, float eps, const float* gamma, const float* beta,
+                           float* scale, float* shift, pdr_stream_t stream) {
+  if (!part0 || C0 <= 0 || tpb0 <= 0 || ldp0 < C0 || B <= 0 || G <= 0 || !scale || !shift)
+    return PDR_EINVAL;
+  if (part1 && (C1 <= 0 || tpb1 <= 0 || ldp1 < C1)) return PDR_EINVAL;
+  const int C = C0 + (part1 ? C1 : 0);
+  if (Cn < 0 || Cn > C || (Cn > 0 && (Cn % G != 0 || !gamma || !beta))) return PDR_EINVAL;
+  if (static_cast<size_t>(C) * 16 > 48 * 1024) return PDR_EUNSUPPORTED;
+  FoldPart p0{part0, ldp0, tpb0, C0, mult0};
+  FoldPart p1{part1, ldp1, tpb1, part1 ? C1 : 0, mult1};
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(1024), static_cast<size_t>(C) * 16,
+                     pdr::as_stream(stream), p0, p1, C, Cn, G, n, eps, gamma, beta, scale, shift);
   return pdr::check_launch();
 }
 

@@ -70,10 +70,15 @@ class Act:
         return li
 
 
-def plain(t2d, B, rows_per_batch, row_div=1):
-    """Act over a contiguous (rows, C) tensor."""
-    rows, C = t2d.shape
-    return Act([(t2d, 0, C, C, row_div)], rows * row_div, B, rows_per_batch)
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def plain(t2d, B, rows_per_batch, row_div=1, C=None):
+    """Act over a (rows, ld) tensor whose first C columns are the channels (ld may be padded)."""
+    rows, ld = t2d.shape
+    C = ld if C is None else C
+    return Act([(t2d, 0, C, ld, row_div)], rows * row_div, B, rows_per_batch)
 
 
 class Conv:
@@ -82,11 +87,15 @@ class Conv:
     def __init__(self, convs):
         convs = [c for c in convs if c is not None]
         ws = [c.weight.detach().reshape(c.weight.shape[0], -1) for c in convs]
-        self.Wt = torch.cat(ws, 0).t().contiguous()
-        dev = self.Wt.device
+        wt = torch.cat(ws, 0).t().contiguous()
+        self.Cin, self.Cout = wt.shape
+        dev = wt.device
+        # leading dimension padded to a multiple of 4 floats: the kernel stages W with 16-B loads
+        self.ldw = _pad4(self.Cout)
+        self.Wt = torch.zeros((self.Cin, self.ldw), dtype=torch.float32, device=dev)
+        self.Wt[:, :self.Cout] = wt
         self.bias = torch.cat([c.bias.detach() if c.bias is not None else torch.zeros(w.shape[0], device=dev)
                                for c, w in zip(convs, ws)]).contiguous()
-        self.Cin, self.Cout = self.Wt.shape
         self.widths = [w.shape[0] for w in ws]
 
 
@@ -96,7 +105,8 @@ def run_layer(act, conv, stats=False, relu_col0=None):
     assert act.C == conv.Cin, (act.C, conv.Cin)
     # rows of wide, odd-width outputs (105, 140, 297 ... = [first | res | key] GEMMs) start on
     # 128-byte boundaries: pad the leading dimension, consumers address columns through `ld`
-    ldy = conv.Cout if (conv.Cout <= 64 or conv.Cout % 32 == 0) else (conv.Cout + 31) // 32 * 32
+    # (narrow outputs: a multiple of 4 floats, so that consumers can stage them with 16-B loads)
+    ldy = _pad4(conv.Cout) if (conv.Cout <= 64 or conv.Cout % 32 == 0) else (conv.Cout + 31) // 32 * 32
     Y = torch.empty((act.P, ldy), dtype=torch.float32, device=conv.Wt.device)
     tm = lib.pdr_fused_layer_tile_rows(act.rpb, conv.Cout)
     tpb = (act.rpb + tm - 1) // tm
@@ -104,7 +114,7 @@ def run_layer(act, conv, stats=False, relu_col0=None):
     if stats:
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
-    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.Cout,
+    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
                                    conv.bias.data_ptr(), conv.Cout, Y.data_ptr(), ldy,
                                    partial.data_ptr() if stats else None,
                                    conv.Cout if relu_col0 is None else relu_col0, _stream()), "fused_layer")
@@ -128,23 +138,22 @@ class Norm:
         self.gamma, self.beta = gn.weight.detach().contiguous(), gn.bias.detach().contiguous()
 
     def fold(self, parts, B, C, n):
-        """parts: [(partial, col0, ncols, tiles_per_batch, mult)] covering C channels in order.
-        Returns (scale, shift) of shape (B, C)."""
+        """parts: [(partial, col0, ncols, tiles_per_batch, mult)] (one or two) covering C channels in order.
+        Returns (scale, shift) of shape (B, C): GroupNorm folded to y = x * scale + shift."""
         lib = _lib.load()
         dev = self.gamma.device
-        stats = torch.empty((B, C, 2), dtype=torch.float64, device=dev)
-        off = 0
-        for partial, col0, ncols, tpb, mult in parts:
-            ldp = partial.shape[1]
-            _lib.check(lib.pdr_gn_reduce(_ptr(partial, 2 * col0), ldp, B, tpb, ncols, float(mult),
-                                         stats.data_ptr(), C, off, _stream()), "gn_reduce")
-            off += ncols
-        assert off == C
+        assert 1 <= len(parts) <= 2 and sum(p[2] for p in parts) == C
         scale = torch.empty((B, C), dtype=torch.float32, device=dev)
         shift = torch.empty((B, C), dtype=torch.float32, device=dev)
-        _lib.check(lib.pdr_gn_finalize(stats.data_ptr(), B, C, self.Cn, self.G, float(n), float(self.eps),
-                                       self.gamma.data_ptr(), self.beta.data_ptr(), scale.data_ptr(),
-                                       shift.data_ptr(), _stream()), "gn_finalize")
+        (pa, ca, na, ta, ma) = parts[0]
+        if len(parts) == 2:
+            (pb, cb, nb, tb, mb) = parts[1]
+            second = (_ptr(pb, 2 * cb), pb.shape[1], tb, nb, float(mb))
+        else:
+            second = (None, 0, 0, 0, 1.0)
+        _lib.check(lib.pdr_gn_fold(_ptr(pa, 2 * ca), pa.shape[1], ta, na, float(ma), *second, B, self.Cn, self.G,
+                                   float(n), float(self.eps), self.gamma.data_ptr(), self.beta.data_ptr(),
+                                   scale.data_ptr(), shift.data_ptr(), _stream()), "gn_fold")
         return scale, shift
 
 
@@ -314,12 +323,12 @@ def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with
     B, n, Cs = feats_cl.shape
     _, m, K = idx.shape
     Cout = Cs + 3 + (3 if with_abs else 0) + (3 if with_centre else 0)
-    out = torch.empty((B * m * K, Cout), dtype=torch.float32, device=feats_cl.device)
+    out = torch.empty((B * m * K, _pad4(Cout)), dtype=torch.float32, device=feats_cl.device)
     _lib.check(_lib.load().pdr_group_build(feats_cl.data_ptr(), Cs, xyz.data_ptr(), new_xyz.data_ptr(),
                                            idx.data_ptr(), counts.data_ptr(), B, n, m, K, int(patch_empty),
-                                           int(with_abs), int(with_centre), out.data_ptr(), _stream()),
-               "group_build")
-    return out
+                                           int(with_abs), int(with_centre), out.data_ptr(), out.shape[1],
+                                           _stream()), "group_build")
+    return out, Cout
 
 
 def gather_rows(src_cl, idx):
@@ -342,12 +351,16 @@ class FusedGroupedBlock:
         self.att = FusedAttention(att)
         self.mlp = FusedMlp(mlp, bank, extra_convs=[self.att.key_conv])
 
-    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset):
+    def neighbours(self, src_xyz, new_xyz):
+        return _ext.ball_query(new_xyz, src_xyz, self.radius, self.nsample)
+
+    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None):
         B, m, _ = new_xyz.shape
-        idx, counts = _ext.ball_query(new_xyz, src_xyz, self.radius, self.nsample)
-        G = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs, self.with_centre)
+        idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
+        G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
+                            self.with_centre)
         K = self.nsample
-        h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K), bank)
+        h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K, C=Cg), bank)
         out = self.att(query_feats_cl.reshape(B * m, -1), h, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K)
         return out.view(B, m, -1)
 
@@ -368,15 +381,15 @@ class FusedKnnFP:
         n2, C = known.shape[1], known_feats_cl.shape[2]
         K = self.K
         d2, idx, _ = _ext.knn_points(unknown, known, K)
-        G = torch.empty((B * n * K, C + 11), dtype=torch.float32, device=unknown.device)
+        G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
         _lib.check(lib.pdr_knn_build(known_feats_cl.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
-                                     idx.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), _stream()),
-                   "knn_build")
-        h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K), bank)
+                                     idx.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
+                                     _stream()), "knn_build")
+        h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
         interp = self.att(unknown_feats_cl.reshape(B * n, -1), h, Y1, part1, tpb1, self.mlp1.extra_col0, None, B, n,
                           K)
         Cs = unknown_feats_cl.shape[2]
-        x2 = Act([(interp, 0, interp.shape[1], interp.shape[1], 1),
+        x2 = Act([(interp, 0, self.att.D, interp.shape[1], 1),
                   (unknown_feats_cl, 0, Cs, Cs, 1), (unknown, 0, 3, 3, 1)], B * n, B, n)
         h2, _, _, _ = self.mlp2(x2, bank, relu_stats_extra=False)
         return materialize(h2).view(B, n, -1)
@@ -453,9 +466,20 @@ class FusedCloudConditionNet:
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
         l_uvw = net.l_uvw
 
+        # the encoder and decoder feature-transfer modules of one level query the SAME clouds with the
+        # same radius / nsample (shipped configs): the ball query is computed once and shared
+        neigh = {}
+
+        def shared(i, blk):
+            key = (i % len(l_uvw), blk.radius, blk.nsample)
+            if key not in neigh:
+                neigh[key] = blk.neighbours(l_uvw[i], l_xyz[i])
+            return neigh[key]
+
         l_xyz, l_feat = [xyz], [feat0]
         for i, sa in enumerate(self.sa):
-            mapped = self.enc_map[i](l_uvw[i], enc_cl[i], l_xyz[i], l_feat[i], bank, subset=False)
+            mapped = self.enc_map[i](l_uvw[i], enc_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
+                                     neigh=shared(i, self.enc_map[i]))
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)
             sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
             new_xyz = gather_rows(l_xyz[i], sel)
@@ -463,10 +487,12 @@ class FusedCloudConditionNet:
             l_xyz.append(new_xyz)
             l_feat.append(sa(l_xyz[i], sa_in, new_xyz, centre, bank, subset=True))
         for i in range(-1, -(len(self.fp) + 1), -1):
-            mapped = self.dec_map[i](l_uvw[i], dec_cl[i], l_xyz[i], l_feat[i], bank, subset=False)
+            mapped = self.dec_map[i](l_uvw[i], dec_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
+                                     neigh=shared(i, self.dec_map[i]))
             fp_in = torch.cat([mapped, l_feat[i]], dim=2)
             l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank)
-        mapped = self.dec_map[0](l_uvw[0], dec_cl[0], l_xyz[0], l_feat[0], bank, subset=False)
+        mapped = self.dec_map[0](l_uvw[0], dec_cl[0], l_xyz[0], l_feat[0], bank, subset=False,
+                                 neigh=shared(0, self.dec_map[0]))
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz, 0, 3, 3, 1)], B * N, B, N)
         Y, part, tpb = run_layer(head_in, self.head1, stats=True)

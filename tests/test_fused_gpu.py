@@ -24,6 +24,13 @@ def _rel(a, b):
     return float(((a - b).abs() / (b.abs() + 1.0)).max())
 
 
+def _conv(W, bias):
+    m = torch.nn.Conv2d(W.shape[1], W.shape[0], 1).to(W.device)
+    m.weight.data = W.reshape(W.shape[0], W.shape[1], 1, 1).clone()
+    m.bias.data = bias.clone()
+    return FN.Conv([m])
+
+
 @pytest.mark.parametrize("P,Cin,Cout,rpb", [(256, 13, 96, 128), (512, 79, 35, 64), (1024, 331, 331, 256),
                                             (96, 3, 32, 32), (4096, 64, 32, 4096), (2048, 163, 3, 1024),
                                             (64, 35, 44, 16), (600, 20, 70, 200)])
@@ -33,7 +40,7 @@ def test_fused_layer_matches_torch(cuda, P, Cin, Cout, rpb):
     c1 = Cin // 2 if Cin > 4 else Cin
     K = 4
     q = torch.randn(P // K, c1, generator=g).to(cuda)                     # broadcast segment (row_div = K)
-    k = torch.randn(P, Cin - c1 + 5, generator=g).to(cuda)               # strided segment (ld > C)
+    k = torch.randn(P, Cin - c1 + 5, generator=g).to(cuda)               # strided segment (ld > C), unaligned
     scale, shift, add = (torch.randn(B, Cin, generator=g).to(cuda) for _ in range(3))
     radd = torch.randn(P, Cin + 2, generator=g).to(cuda)
     W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
@@ -42,8 +49,7 @@ def test_fused_layer_matches_torch(cuda, P, Cin, Cout, rpb):
     for pre, post in ((False, True), (True, False)):
         act = FN.Act(segs, P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin, radd=(radd, 1, Cin + 2),
                      pre_relu=pre, post_relu=post)
-        conv = FN.Conv.__new__(FN.Conv)
-        conv.Wt, conv.bias, conv.Cin, conv.Cout = W.t().contiguous(), bias, Cin, Cout
+        conv = _conv(W, bias)
         Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=Cout // 2)
         x = torch.cat([q.repeat_interleave(K, 0)] + ([k[:, 3:3 + Cin - c1]] if Cin > c1 else []), 1)
         bidx = torch.arange(P, device=cuda) // rpb
@@ -70,8 +76,7 @@ def test_groupnorm_fold_matches_torch_groupnorm(cuda):
     x = (torch.randn(B * rpb, C, generator=g) * 2 + 0.7).to(cuda)
     from point_diffusion_refinement_amd.pointnet2_ops.attention import MyGroupNorm
     gn = fill_deterministic(MyGroupNorm(32, C), 9).to(cuda)
-    ident = FN.Conv.__new__(FN.Conv)
-    ident.Wt, ident.bias, ident.Cin, ident.Cout = torch.eye(C, device=cuda), torch.zeros(C, device=cuda), C, C
+    ident = _conv(torch.eye(C, device=cuda), torch.zeros(C, device=cuda))
     Y, part, tpb = FN.run_layer(FN.plain(x, B, rpb), ident, stats=True)
     scale, shift = FN.Norm(gn).fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
     got = FN.materialize(FN.Act([(Y, 0, C, Y.shape[1], 1)], B * rpb, B, rpb, scale=scale, shift=shift))
@@ -138,3 +143,34 @@ def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
     torch.manual_seed(78)
     b = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=False).sample((2, 2048, 3), cond2, label2)
     assert ((a - b).abs() / (b.abs() + 1.0)).max() < 1e-3
+
+
+@pytest.mark.parametrize("P,Cin,Cout,rpb", [(512, 13, 96, 256), (1024, 331, 587, 512), (256, 64, 32, 256),
+                                            (2048, 171, 140, 1024), (128, 41, 105, 128)])
+def test_fused_layer_vector_staging(cuda, P, Cin, Cout, rpb):
+    """16-B aligned, 4-float-padded sources take the float4 staging path; same answer as torch."""
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    B = P // rpb
+    ld = (Cin + 3) // 4 * 4
+    x = torch.zeros(P, ld, device=cuda)
+    x[:, :Cin] = torch.randn(P, Cin, generator=g).to(cuda)
+    x[:, Cin:] = float("nan")                                              # padding must never leak in
+    scale, shift, add = (torch.randn(B, Cin, generator=g).to(cuda) for _ in range(3))
+    radd = torch.zeros(P, ld, device=cuda)
+    radd[:, :Cin] = torch.randn(P, Cin, generator=g).to(cuda)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    bias = torch.randn(Cout, generator=g).to(cuda)
+    conv = _conv(W, bias)
+    bidx = torch.arange(P, device=cuda) // rpb
+    for use_radd in (False, True):
+        act = FN.Act([(x, 0, Cin, ld, 1)], P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin,
+                     radd=(radd, 0, ld) if use_radd else None, post_relu=True)
+        Y, part, tpb = FN.run_layer(act, conv, stats=True)
+        ref = (x[:, :Cin] * scale[bidx] + shift[bidx]).relu() + add[bidx]
+        if use_radd:
+            ref = ref + radd[:, :Cin]
+        ref = ref.double() @ W.t().double() + bias.double()
+        assert torch.isfinite(Y[:, :Cout]).all()
+        assert _rel(Y[:, :Cout].double(), ref) < 2e-5
+        got = part.view(B, tpb, Cout, 2).double().sum(1)
+        assert _rel(got[..., 0], ref.view(B, rpb, Cout).sum(1)) < 1e-4

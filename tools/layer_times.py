@@ -42,7 +42,7 @@ def instrument(records):
 
     FN.run_layer = wrap("fused_layer", FN.run_layer, layer_meta)
     FN.group_build = wrap("group_build", FN.group_build,
-                          lambda a, k, out: dict(P=out.shape[0], Cin=0, Cout=out.shape[1], bytes=4 * out.numel(),
+                          lambda a, k, out: dict(P=out[0].shape[0], Cin=0, Cout=out[1], bytes=4 * out[0].numel(),
                                                  flops=0))
     FN.materialize = wrap("apply_act", FN.materialize,
                           lambda a, k, out: dict(P=out.shape[0], Cin=0, Cout=out.shape[1], bytes=8 * out.numel(),
