@@ -375,12 +375,12 @@ class FusedKnnFP:
         self.mlp1 = FusedMlp(fp.mlp1, bank, extra_convs=[self.att.key_conv], cond_kind="c2")
         self.mlp2 = FusedMlp(fp.mlp2, bank)
 
-    def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank):
+    def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank, knn=None):
         lib = _lib.load()
         B, n, _ = unknown.shape
         n2, C = known.shape[1], known_feats_cl.shape[2]
         K = self.K
-        d2, idx, _ = _ext.knn_points(unknown, known, K)
+        d2, idx = knn if knn is not None else _ext.knn_points(unknown, known, K)[:2]
         G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
         _lib.check(lib.pdr_knn_build(known_feats_cl.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
                                      idx.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
@@ -424,6 +424,12 @@ class FusedCloudConditionNet:
         b.pack()
         self.enc_cl = self.dec_cl = None
         self._synced = False
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=next(self.net.parameters()).device)
+        return self._side
 
     def sync_condition(self):
         """Channel-last copies of the retained condition features.  Called once per batch, after the
@@ -466,33 +472,58 @@ class FusedCloudConditionNet:
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
         l_uvw = net.l_uvw
 
-        # the encoder and decoder feature-transfer modules of one level query the SAME clouds with the
-        # same radius / nsample (shipped configs): the ball query is computed once and shared
-        neigh = {}
+        # ---- geometry prepass on a side stream -------------------------------------------------
+        # FPS chain, every ball query and every kNN search depend on coordinates only.  They are
+        # latency / VALU-bound and (FPS) occupy 32 of 256 CUs, so they run beside the GEMMs of the
+        # first feature-transfer block instead of in front of each consumer.  The encoder and decoder
+        # feature-transfer modules of one level query the SAME clouds with the same radius / nsample
+        # (shipped configs): that ball query is computed once and shared.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        nlev = len(self.sa)
+        l_xyz, sels, fm_neigh, sa_neigh, knn = [xyz], [], {}, [], {}
 
-        def shared(i, blk):
-            key = (i % len(l_uvw), blk.radius, blk.nsample)
-            if key not in neigh:
-                neigh[key] = blk.neighbours(l_uvw[i], l_xyz[i])
-            return neigh[key]
+        def fm_key(i, blk):
+            return (i % (nlev + 1), blk.radius, blk.nsample)
 
-        l_xyz, l_feat = [xyz], [feat0]
+        with torch.cuda.stream(side):
+            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
+            ev_first = torch.cuda.Event()
+            ev_first.record(side)
+            for i, sa in enumerate(self.sa):
+                sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
+                sels.append(sel)
+                l_xyz.append(gather_rows(l_xyz[i], sel))
+                sa_neigh.append(sa.neighbours(l_xyz[i], l_xyz[i + 1]))
+            for i in range(nlev + 1):
+                for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
+                    if fm_key(i, blk) not in fm_neigh:
+                        fm_neigh[fm_key(i, blk)] = blk.neighbours(l_uvw[i], l_xyz[i])
+            for i in range(-1, -(len(self.fp) + 1), -1):
+                d2, idx, _ = _ext.knn_points(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
+                knn[i] = (d2, idx)
+            ev_all = torch.cuda.Event()
+            ev_all.record(side)
+
+        # ---- feature path ------------------------------------------------------------------------
+        main.wait_event(ev_first)
+        l_feat = [feat0]
         for i, sa in enumerate(self.sa):
             mapped = self.enc_map[i](l_uvw[i], enc_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
-                                     neigh=shared(i, self.enc_map[i]))
+                                     neigh=fm_neigh[fm_key(i, self.enc_map[i])])
+            if i == 0:
+                main.wait_event(ev_all)
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)
-            sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
-            new_xyz = gather_rows(l_xyz[i], sel)
-            centre = gather_rows(sa_in, sel)
-            l_xyz.append(new_xyz)
-            l_feat.append(sa(l_xyz[i], sa_in, new_xyz, centre, bank, subset=True))
+            centre = gather_rows(sa_in, sels[i])
+            l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i]))
         for i in range(-1, -(len(self.fp) + 1), -1):
             mapped = self.dec_map[i](l_uvw[i], dec_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
-                                     neigh=shared(i, self.dec_map[i]))
+                                     neigh=fm_neigh[fm_key(i, self.dec_map[i])])
             fp_in = torch.cat([mapped, l_feat[i]], dim=2)
-            l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank)
+            l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i])
         mapped = self.dec_map[0](l_uvw[0], dec_cl[0], l_xyz[0], l_feat[0], bank, subset=False,
-                                 neigh=shared(0, self.dec_map[0]))
+                                 neigh=fm_neigh[fm_key(0, self.dec_map[0])])
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz, 0, 3, 3, 1)], B * N, B, N)
         Y, part, tpb = run_layer(head_in, self.head1, stats=True)
