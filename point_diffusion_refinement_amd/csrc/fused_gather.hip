@@ -219,3 +219,118 @@ extern "C" int pdr_gather_rows(const float* src, const int* idx, int B, int n, i
                      pdr::as_stream(stream), src, n, C, idx, m, total, out);
   return pdr::check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// gather_add: first 1x1 conv of a grouped block WITHOUT the grouped tensor.
+//
+// The grouped input of QueryAndGroup / group_knn is a gather of per-point rows plus per-query
+// terms, and the conv is linear, so for position p = (b, j, k) with neighbour a = idx[p]:
+//     conv([feat[a] | xyz[a]-c_j | xyz[a] | c_j]) = U[b,a,:] + V[b,j,:]
+//         U = [feat | xyz] . [W_f ; W_rel + W_abs]   (one row per SOURCE point,  n  rows)
+//         V = c . (W_ctr - W_rel) + bias             (one row per QUERY,         m  rows)
+//     kNN: conv([feat[a] | d2 | w | y[a] | y[a]-x_i | x_i]) = U[b,a,:] + V[b,i,:] + d2 r1 + w r2
+// U and V are small GEMMs over n and m rows (fused_layer); this kernel produces the (m K)-row
+// output with one gather + add per element and the GroupNorm moments of the result.  It removes
+// 2 P Cin Cout flops (37 % of a reverse step's GEMM work) and the P x Cin grouped tensor.
+// Empty balls (subset=False): the reference substitutes the query itself with a zero feature:
+// Y = V0[b,j,:] = c . (W_abs + W_ctr) + bias.
+//
+// One workgroup = 128 positions (32 per wave, one at a time per wave: idx / count are wave-uniform
+// scalars), lanes stride the columns in float4: every U / V / Y access is a contiguous row segment.
+__global__ __launch_bounds__(256) void gather_add_kernel(
+    const float* __restrict__ U, int ldu, int n_src, const float* __restrict__ V,
+    const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
+    const float* __restrict__ s1, const float* __restrict__ r1, const float* __restrict__ s2,
+    const float* __restrict__ r2, int rows_per_batch, int K, int Cout, float* __restrict__ Y, int ldy,
+    float* __restrict__ partial, int relu_col0) {
+  constexpr int TM = 128;
+  __shared__ float red[4][256][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tpb = (rows_per_batch + TM - 1) / TM;
+  const int b = blockIdx.x / tpb, tb = blockIdx.x - b * tpb;
+  const long row0 = static_cast<long>(b) * rows_per_batch + static_cast<long>(tb) * TM;
+  const int nvalid = min(TM, rows_per_batch - tb * TM);
+  const float* Ub = U + static_cast<long>(b) * n_src * ldu;
+  for (int c0 = 0; c0 < Cout; c0 += 256) {
+    const int c = c0 + 4 * lane;
+    const bool cok = c < Cout;   // Cout is padded to a multiple of 4 in ldu / ldv / ldy
+    float4 q1 = make_float4(0, 0, 0, 0), q2 = make_float4(0, 0, 0, 0);
+    if (cok && r1) q1 = *reinterpret_cast<const float4*>(r1 + c);
+    if (cok && r2) q2 = *reinterpret_cast<const float4*>(r2 + c);
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int r = wave; r < nvalid; r += 4) {
+      const long p = row0 + r;
+      const int a = __builtin_amdgcn_readfirstlane(idx[p]);
+      const long qrow = p / K;
+      const bool empty = counts && __builtin_amdgcn_readfirstlane(counts[qrow]) <= 0;
+      float4 y = make_float4(0, 0, 0, 0);
+      if (cok) {
+        if (empty) {
+          y = *reinterpret_cast<const float4*>(V0 + qrow * ldv + c);
+        } else {
+          const float4 u = *reinterpret_cast<const float4*>(Ub + static_cast<long>(a) * ldu + c);
+          const float4 v = *reinterpret_cast<const float4*>(V + qrow * ldv + c);
+          y = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+          if (s1) {
+            const float t = s1[p];
+            y.x = __builtin_fmaf(t, q1.x, y.x); y.y = __builtin_fmaf(t, q1.y, y.y);
+            y.z = __builtin_fmaf(t, q1.z, y.z); y.w = __builtin_fmaf(t, q1.w, y.w);
+          }
+          if (s2) {
+            const float t = s2[p];
+            y.x = __builtin_fmaf(t, q2.x, y.x); y.y = __builtin_fmaf(t, q2.y, y.y);
+            y.z = __builtin_fmaf(t, q2.z, y.z); y.w = __builtin_fmaf(t, q2.w, y.w);
+          }
+        }
+        *reinterpret_cast<float4*>(Y + p * ldy + c) = y;
+        const float e[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f = (c + j >= relu_col0) ? fmaxf(e[j], 0.0f) : e[j];
+          a1[j] += f;
+          a2[j] = __builtin_fmaf(f, f, a2[j]);
+        }
+      }
+    }
+    if (partial) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[wave][4 * lane + j][0] = a1[j];
+        red[wave][4 * lane + j][1] = a2[j];
+      }
+      __syncthreads();
+      const int cc = c0 + threadIdx.x;
+      if (cc < Cout) {
+        const float t1 = (red[0][threadIdx.x][0] + red[1][threadIdx.x][0]) +
+                         (red[2][threadIdx.x][0] + red[3][threadIdx.x][0]);
+        const float t2 = (red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) +
+                         (red[2][threadIdx.x][1] + red[3][threadIdx.x][1]);
+        float* o = partial + (static_cast<long>(blockIdx.x) * Cout + cc) * 2;
+        o[0] = t1;
+        o[1] = t2;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Y (B*rows_per_batch, Cout; ld ldy) = U[b, idx[p]] + V[p / K] (+ s1[p] r1 + s2[p] r2), empty balls -> V0.
+// U (B, n_src, ldu), V / V0 (B*rows_per_batch/K, ldv); all leading dimensions multiples of 4, 16-B
+// aligned.  partial: NULL or (B * ceil(rows_per_batch / 128), Cout, 2) moments as in pdr_fused_layer.
+extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V, const float* V0,
+                              int ldv, const int* idx, const int* counts, const float* s1,
+                              const float* r1, const float* s2, const float* r2, int B,
+                              int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
+                              int relu_col0, pdr_stream_t stream) {
+  if (!U || !V || !idx || !Y || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 || n_src <= 0)
+    return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  if (rows_per_batch % K != 0 || (counts && !V0) || (s1 && !r1) || (s2 && !r2)) return PDR_EINVAL;
+  const int c4 = (Cout + 3) & ~3;
+  if (ldu % 4 || ldv % 4 || ldy % 4 || ldu < c4 || ldv < c4 || ldy < c4) return PDR_EINVAL;
+  const int tpb = (rows_per_batch + 127) / 128;
+  hipLaunchKernelGGL(gather_add_kernel, dim3(static_cast<unsigned>(B) * tpb), dim3(256), 0,
+                     pdr::as_stream(stream), U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2,
+                     rows_per_batch, K, Cout, Y, ldy, partial, relu_col0);
+  return pdr::check_launch();
+}

@@ -35,6 +35,11 @@ from ..pointnet2_ops.attention import MyGroupNorm
 from .models.pointnet2_ssg_sem import calc_t_emb
 
 
+# First conv of every grouped block through per-point U / V tables + pdr_gather_add instead of a GEMM
+# over the materialised grouped tensor (see SplitFirstConv).  False = reference-shaped evaluation.
+USE_SPLIT_FIRST = True
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -244,27 +249,31 @@ class FusedMlp:
     def __call__(self, x, bank, relu_stats_extra=True):
         """x: Act over the grouped input.  Returns (h Act [final activation incl. residual], Y1, part1, tpb1)
         where Y1 holds [first conv | res conv | extra convs] columns."""
-        n = x.rpb
         relu0 = self.extra_col0 if relu_stats_extra else None
-        Y, part, tpb = run_layer(x, self.first, stats=True, relu_col0=relu0)
-        Y1, part1, tpb1 = Y, part, tpb
+        Y1, part1, tpb1 = run_layer(x, self.first, stats=True, relu_col0=relu0)
+        return self.after_first(Y1, part1, tpb1, x.P, x.B, x.rpb, bank, x)
+
+    def after_first(self, Y1, part1, tpb1, P, B, rpb, bank, x=None):
+        """Everything behind the first GEMM, given its output (however it was produced)."""
+        Y, part, tpb = Y1, part1, tpb1
         ld = Y.shape[1]
-        cur = Act([(Y, 0, self.C1, ld, 1)], x.P, x.B, x.rpb)
+        cur = Act([(Y, 0, self.C1, ld, 1)], P, B, rpb)
         for i, norm in enumerate(self.norms):
             C = cur.C
-            scale, shift = norm.fold([(part, 0, C, tpb, 1.0)], x.B, C, n)
+            scale, shift = norm.fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
             cur.scale, cur.shift, cur.post_relu = scale, shift, True
             inj = bank.get(self.inject.get(i))
             if inj is not None:
                 cur.add, cur.add_ld = inj[0][:, inj[1]:], inj[2]
             if i < len(self.rest):
                 Y, part, tpb = run_layer(cur, self.rest[i], stats=True)
-                cur = Act([(Y, 0, self.rest[i].Cout, Y.shape[1], 1)], x.P, x.B, x.rpb)
+                cur = Act([(Y, 0, self.rest[i].Cout, Y.shape[1], 1)], P, B, rpb)
         if self.has_res:
             if self.res_col0 is not None:
                 cur.radd = (Y1, self.res_col0, ld)
             else:
-                if len(x.segs) != 1 or x.scale is not None or x.pre_relu or x.post_relu or x.add is not None:
+                if x is None or len(x.segs) != 1 or x.scale is not None or x.pre_relu or x.post_relu or \
+                        x.add is not None:
                     raise NotImplementedError("identity residual over a composite input")
                 t, off, C, ldx, div = x.segs[0]
                 assert div == 1
@@ -319,6 +328,79 @@ class FusedAttention:
         return out
 
 
+class _RawConv:
+    """Conv-like view over explicit (Wt, bias) tensors."""
+
+    def __init__(self, Wt, bias, Cout):
+        self.Wt, self.bias = Wt.contiguous(), bias.contiguous()
+        self.Cin, self.ldw, self.Cout = Wt.shape[0], Wt.shape[1], Cout
+
+
+class SplitFirstConv:
+    """First 1x1 conv of a grouped block evaluated WITHOUT the grouped (P x Cin) tensor.
+
+    The grouped input is a gather of per-point rows plus per-query terms and the conv is linear:
+        ball:  conv([feat[a] | xyz[a]-c | xyz[a] | c])            = U[a] + V[j]
+               U = [feat | xyz].[W_f ; W_rel+W_abs]  (n rows),  V = c.(W_ctr-W_rel) + bias  (m rows),
+               empty ball (subset=False: neighbour := the query, zero feature): V0 = c.(W_abs+W_ctr) + bias
+        kNN:   conv([feat[a] | d2 | w | y[a] | y[a]-x | x])        = U[a] + V[i] + d2 r1 + w r2
+               U = [feat | y].[W_f ; W_abs+W_rel],  V = x.(W_x-W_rel) + bias,  r1 / r2 = the d2 / weight rows
+    U and V are two small GEMMs over the n source / m query rows; pdr_gather_add then writes the
+    (m K)-row result and its GroupNorm moments in one pass.  Saves 2 P Cin Cout flops and the grouped
+    tensor; the result differs from the direct conv only by fp32 summation order."""
+
+    def __init__(self, first, Cs, kind, with_abs=True, with_centre=True):
+        Wt, bias, Cout, dev = first.Wt, first.bias, first.Cout, first.Wt.device
+        self.Cout, self.ld = Cout, first.ldw
+        zero3 = torch.zeros((3, first.ldw), device=dev)
+        zb = torch.zeros_like(bias)
+        pad_bias = torch.zeros(first.ldw, device=dev)
+        pad_bias[:Cout] = bias
+        W_f = Wt[:Cs]
+        if kind == 'ball':
+            W_rel = Wt[Cs:Cs + 3]
+            o = Cs + 3
+            W_abs = Wt[o:o + 3] if with_abs else zero3
+            o += 3 if with_abs else 0
+            W_ctr = Wt[o:o + 3] if with_centre else zero3
+            self.U = _RawConv(torch.cat([W_f, W_rel + W_abs], 0), zb, Cout)
+            self.V = _RawConv(W_ctr - W_rel, bias, Cout)
+            self.V0 = _RawConv(W_abs + W_ctr, bias, Cout)
+            self.r1 = self.r2 = None
+        else:
+            self.r1, self.r2 = Wt[Cs].contiguous(), Wt[Cs + 1].contiguous()
+            W_abs, W_rel, W_x = Wt[Cs + 2:Cs + 5], Wt[Cs + 5:Cs + 8], Wt[Cs + 8:Cs + 11]
+            self.U = _RawConv(torch.cat([W_f, W_abs + W_rel], 0), zb, Cout)
+            self.V = _RawConv(W_x - W_rel, bias, Cout)
+            self.V0 = None
+
+    def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None):
+        """-> (Y1 (B*m*K, ld), partial, tiles_per_batch)."""
+        lib = _lib.load()
+        B, n, Cs = src_feats_cl.shape
+        m = query_xyz.shape[1]
+        u_in = Act([(src_feats_cl, 0, Cs, Cs, 1), (src_xyz, 0, 3, 3, 1)], B * n, B, n)
+        U, _, _ = run_layer(u_in, self.U)
+        q_in = plain(query_xyz.reshape(B * m, 3), B, m)
+        V, _, _ = run_layer(q_in, self.V)
+        V0 = None
+        if counts is not None:
+            V0, _, _ = run_layer(q_in, self.V0)
+        assert U.shape[1] == V.shape[1]
+        ld = U.shape[1]
+        rpb = m * K
+        tpb = (rpb + 127) // 128
+        Y = torch.empty((B * rpb, ld), dtype=torch.float32, device=U.device)
+        partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
+        _lib.check(lib.pdr_gather_add(
+            U.data_ptr(), ld, n, V.data_ptr(), V0.data_ptr() if V0 is not None else None, ld, idx32.data_ptr(),
+            counts.data_ptr() if counts is not None else None,
+            s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
+            s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
+            B, rpb, K, self.Cout, Y.data_ptr(), ld, partial.data_ptr(), relu_col0, _stream()), "gather_add")
+        return Y, partial, tpb
+
+
 def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with_centre):
     B, n, Cs = feats_cl.shape
     _, m, K = idx.shape
@@ -350,6 +432,7 @@ class FusedGroupedBlock:
         self.with_abs, self.with_centre = grouper.include_abs_coordinate, grouper.include_center_coordinate
         self.att = FusedAttention(att)
         self.mlp = FusedMlp(mlp, bank, extra_convs=[self.att.key_conv])
+        self.split = None   # built lazily (needs the source feature width)
 
     def neighbours(self, src_xyz, new_xyz):
         return _ext.ball_query(new_xyz, src_xyz, self.radius, self.nsample)
@@ -357,10 +440,18 @@ class FusedGroupedBlock:
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None):
         B, m, _ = new_xyz.shape
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
-        G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
-                            self.with_centre)
         K = self.nsample
-        h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K, C=Cg), bank)
+        if USE_SPLIT_FIRST:
+            if self.split is None:
+                self.split = SplitFirstConv(self.mlp.first, src_feats_cl.shape[2], 'ball', self.with_abs,
+                                            self.with_centre)
+            Y1, part1, tpb1 = self.split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
+                                         self.mlp.extra_col0)
+            h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
+        else:
+            G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
+                                self.with_centre)
+            h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K, C=Cg), bank)
         out = self.att(query_feats_cl.reshape(B * m, -1), h, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K)
         return out.view(B, m, -1)
 
@@ -374,6 +465,7 @@ class FusedKnnFP:
         # mlp1's fc_condition is fed the SECOND condition (class) embedding (pointnet2_modules.py:791-793)
         self.mlp1 = FusedMlp(fp.mlp1, bank, extra_convs=[self.att.key_conv], cond_kind="c2")
         self.mlp2 = FusedMlp(fp.mlp2, bank)
+        self.split = None
 
     def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank, knn=None):
         lib = _lib.load()
@@ -381,11 +473,21 @@ class FusedKnnFP:
         n2, C = known.shape[1], known_feats_cl.shape[2]
         K = self.K
         d2, idx = knn if knn is not None else _ext.knn_points(unknown, known, K)[:2]
-        G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
-        _lib.check(lib.pdr_knn_build(known_feats_cl.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
-                                     idx.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
-                                     _stream()), "knn_build")
-        h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
+        if USE_SPLIT_FIRST:
+            if self.split is None:
+                self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
+            # inverse-(squared-)distance weights exactly as group_knn: 1/(d2+1e-8), normalised over K
+            recip = 1.0 / (d2 + 1e-8)
+            wgt = recip / torch.sum(recip, dim=2, keepdim=True)
+            Y1, part1, tpb1 = self.split(known_feats_cl, known, unknown, idx.int(), None, K, self.mlp1.extra_col0,
+                                         s1=d2.contiguous(), s2=wgt.contiguous())
+            h, Y1, part1, tpb1 = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
+        else:
+            G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
+            _lib.check(lib.pdr_knn_build(known_feats_cl.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
+                                         idx.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
+                                         _stream()), "knn_build")
+            h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
         interp = self.att(unknown_feats_cl.reshape(B * n, -1), h, Y1, part1, tpb1, self.mlp1.extra_col0, None, B, n,
                           K)
         Cs = unknown_feats_cl.shape[2]

@@ -100,7 +100,11 @@ def _cached_eps(net, fused, x, cond, ts, label):
     return got, ref
 
 
-def test_fused_network_small_config(cuda):
+@pytest.mark.parametrize("split_first", [True, False])
+def test_fused_network_small_config(cuda, split_first, monkeypatch):
+    """split_first=True: first conv of each grouped block via per-point U/V tables + gather_add;
+    False: GEMM over the materialised grouped tensor (group_build / knn_build).  Both must match torch."""
+    monkeypatch.setattr(FN, "USE_SPLIT_FIRST", split_first)
     net, fused = _pair(small_fused_config(), 21, cuda)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 256, 3, generator=g).to(cuda)
