@@ -54,18 +54,8 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
     int* row = oi + static_cast<size_t>(j) * nsample;
     int cnt = 0;
     int first = 0;
-#pragma unroll
-    for (int c = 0; c < nch; ++c) {
-      float x, y, z;
-      if constexpr (RESIDENT) {
-        x = px[c]; y = py[c]; z = pz[c];
-      } else {
-        const int k = c * 64 + lane;
-        const bool ok = k < n;
-        x = ok ? p[k * 3 + 0] : __builtin_inff();
-        y = ok ? p[k * 3 + 1] : __builtin_inff();
-        z = ok ? p[k * 3 + 2] : __builtin_inff();
-      }
+    // body of one 64-point chunk; `x,y,z` = this lane's point of the chunk
+    auto scan = [&](int c, float x, float y, float z) {
       const float dx = qx - x, dy = qy - y, dz = qz - z;
       const float d2 = PDR_SUM3(dx, dy, dz);
       const bool hit = d2 < radius2;
@@ -77,7 +67,21 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
                                   __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
         if (hit && pos < nsample) row[pos] = c * 64 + lane;
         cnt += __builtin_popcountll(mask);
-        if (cnt >= nsample) break;
+      }
+    };
+    if constexpr (RESIDENT) {
+      // constant trip count + wave-uniform guard (no `break`): the loop must unroll completely,
+      // otherwise px/py/pz are indexed dynamically and land in scratch memory
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (cnt < nsample) scan(c, px[c], py[c], pz[c]);
+      }
+    } else {
+      for (int c = 0; c < nch && cnt < nsample; ++c) {
+        const int k = c * 64 + lane;
+        const bool ok = k < n;
+        scan(c, ok ? p[k * 3 + 0] : __builtin_inff(), ok ? p[k * 3 + 1] : __builtin_inff(),
+             ok ? p[k * 3 + 2] : __builtin_inff());
       }
     }
     const int filled = cnt < nsample ? cnt : nsample;

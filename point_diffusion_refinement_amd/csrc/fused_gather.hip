@@ -91,40 +91,54 @@ __global__ __launch_bounds__(256) void knn_build_kernel(
   }
 }
 
-// thread per (row = b*npoint + j, d); lanes run over d -> coalesced reads of scores/values
+// One lane per (query row, 4 channels): scores and values are streamed ONCE as float4 with an
+// online softmax (running max m, normaliser l, accumulator rescaled by exp(m_old - m_new)); the
+// result equals softmax-then-sum up to fp32 rounding.
 __global__ __launch_bounds__(256) void attention_pool_kernel(
     const float* __restrict__ scores, int lds, const float* __restrict__ values, int ldv,
     const float* __restrict__ vscale, const float* __restrict__ vshift, int v_relu,
     const int* __restrict__ counts, int K, int D, int npoint, long rows, float* __restrict__ out) {
+  const int D4 = D >> 2;
   const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-  if (t >= rows * D) return;
-  const long row = t / D;
-  const int d = static_cast<int>(t - row * D);
+  if (t >= rows * D4) return;
+  const long row = t / D4;
+  const int d = static_cast<int>(t - row * D4) * 4;
   const int b = static_cast<int>(row / npoint);
   int cnt = K;
   if (counts) {
     cnt = counts[row];
     cnt = cnt < 1 ? 1 : cnt;             // attention.py:85 clamp(min=1)
   }
-  const float sc = vscale ? vscale[static_cast<long>(b) * D + d] : 1.0f;
-  const float sh = vshift ? vshift[static_cast<long>(b) * D + d] : 0.0f;
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+  if (vscale) sc = *reinterpret_cast<const float4*>(vscale + static_cast<long>(b) * D + d);
+  if (vshift) sh = *reinterpret_cast<const float4*>(vshift + static_cast<long>(b) * D + d);
+  const float lo = v_relu ? 0.0f : -__builtin_inff();
   const float* s = scores + row * K * lds + d;
   const float* v = values + row * K * ldv + d;
-  float mx = -__builtin_inff();
+  float m[4], l[4], acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { m[j] = -__builtin_inff(); l[j] = 0.0f; acc[j] = 0.0f; }
+#pragma unroll 4
   for (int k = 0; k < K; ++k) {
-    const float sk = k < cnt ? s[static_cast<long>(k) * lds] : -1e9f;
-    mx = fmaxf(mx, sk);
+    float4 sk = *reinterpret_cast<const float4*>(s + static_cast<long>(k) * lds);
+    const float4 vk = *reinterpret_cast<const float4*>(v + static_cast<long>(k) * ldv);
+    if (k >= cnt) sk = make_float4(-1e9f, -1e9f, -1e9f, -1e9f);   // masked slots: exactly -1e9
+    const float se[4] = {sk.x, sk.y, sk.z, sk.w};
+    const float ve[4] = {vk.x, vk.y, vk.z, vk.w};
+    const float sce[4] = {sc.x, sc.y, sc.z, sc.w}, she[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mn = fmaxf(m[j], se[j]);
+      const float corr = expf(m[j] - mn);      // exp(-inf) = 0 on the first slot
+      const float w = expf(se[j] - mn);
+      const float val = fmaxf(__builtin_fmaf(ve[j], sce[j], she[j]), lo);
+      l[j] = __builtin_fmaf(l[j], corr, w);
+      acc[j] = __builtin_fmaf(acc[j], corr, val * w);
+      m[j] = mn;
+    }
   }
-  float den = 0.0f, num = 0.0f;
-  for (int k = 0; k < K; ++k) {
-    const float sk = k < cnt ? s[static_cast<long>(k) * lds] : -1e9f;
-    const float w = expf(sk - mx);
-    float val = __builtin_fmaf(v[static_cast<long>(k) * ldv], sc, sh);
-    if (v_relu) val = fmaxf(val, 0.0f);
-    den += w;
-    num = __builtin_fmaf(val, w, num);
-  }
-  out[t] = num / den;
+  *reinterpret_cast<float4*>(out + row * D + d) =
+      make_float4(acc[0] / l[0], acc[1] / l[1], acc[2] / l[2], acc[3] / l[3]);
 }
 
 // rows of a channel-last matrix: out[b, j, :] = src[b, idx[b,j], :]
@@ -203,7 +217,8 @@ extern "C" int pdr_attention_pool(const float* scores, int lds, const float* val
   if (B == 0 || npoint == 0) return PDR_OK;
   if (!scores || !values || !out) return PDR_EINVAL;
   const long rows = static_cast<long>(B) * npoint;
-  hipLaunchKernelGGL(attention_pool_kernel, dim3(blocks_for(rows * D)), dim3(256), 0,
+  if (D % 4 || lds % 4 || ldv % 4) return PDR_EUNSUPPORTED;
+  hipLaunchKernelGGL(attention_pool_kernel, dim3(blocks_for(rows * (D / 4))), dim3(256), 0,
                      pdr::as_stream(stream), scores, lds, values, ldv, vscale, vshift, v_relu, counts, K,
                      D, npoint, rows, out);
   return pdr::check_launch();
@@ -235,8 +250,10 @@ extern "C" int pdr_gather_rows(const float* src, const int* idx, int B, int n, i
 // Empty balls (subset=False): the reference substitutes the query itself with a zero feature:
 // Y = V0[b,j,:] = c . (W_abs + W_ctr) + bias.
 //
-// One workgroup = 128 positions (32 per wave, one at a time per wave: idx / count are wave-uniform
-// scalars), lanes stride the columns in float4: every U / V / Y access is a contiguous row segment.
+// One workgroup = 128 positions; each wave owns 32 CONSECUTIVE positions whose neighbour indices /
+// empty flags / per-position scalars are fetched with one coalesced load and then broadcast from
+// registers (v_readlane), four positions at a time, so 8 row loads are in flight per wave before the
+// first add.  Lanes stride the columns in float4: every U / V / Y access is a contiguous row segment.
 __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ U, int ldu, int n_src, const float* __restrict__ V,
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
@@ -251,44 +268,60 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
   const long row0 = static_cast<long>(b) * rows_per_batch + static_cast<long>(tb) * TM;
   const int nvalid = min(TM, rows_per_batch - tb * TM);
   const float* Ub = U + static_cast<long>(b) * n_src * ldu;
+  // this wave's 32 positions: wrow0 .. wrow0 + 31 (clamped to the tile for the loads, masked later)
+  const int wr0 = wave * 32;
+  const int myr = min(wr0 + (lane & 31), nvalid - 1);
+  const long myp = row0 + myr;
+  const int my_idx = idx[myp];
+  const int my_empty = (counts && counts[myp / K] <= 0) ? 1 : 0;
+  const float my_s1 = s1 ? s1[myp] : 0.0f;
+  const float my_s2 = s2 ? s2[myp] : 0.0f;
+  const int nrows = max(0, min(32, nvalid - wr0));   // uniform
+
   for (int c0 = 0; c0 < Cout; c0 += 256) {
     const int c = c0 + 4 * lane;
-    const bool cok = c < Cout;   // Cout is padded to a multiple of 4 in ldu / ldv / ldy
+    const bool cok = c < Cout;   // row widths are padded to a multiple of 4 in ldu / ldv / ldy
+    const int cc = cok ? c : 0;
     float4 q1 = make_float4(0, 0, 0, 0), q2 = make_float4(0, 0, 0, 0);
     if (cok && r1) q1 = *reinterpret_cast<const float4*>(r1 + c);
     if (cok && r2) q2 = *reinterpret_cast<const float4*>(r2 + c);
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (int r = wave; r < nvalid; r += 4) {
-      const long p = row0 + r;
-      const int a = __builtin_amdgcn_readfirstlane(idx[p]);
-      const long qrow = p / K;
-      const bool empty = counts && __builtin_amdgcn_readfirstlane(counts[qrow]) <= 0;
-      float4 y = make_float4(0, 0, 0, 0);
-      if (cok) {
-        if (empty) {
-          y = *reinterpret_cast<const float4*>(V0 + qrow * ldv + c);
-        } else {
-          const float4 u = *reinterpret_cast<const float4*>(Ub + static_cast<long>(a) * ldu + c);
-          const float4 v = *reinterpret_cast<const float4*>(V + qrow * ldv + c);
-          y = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
-          if (s1) {
-            const float t = s1[p];
-            y.x = __builtin_fmaf(t, q1.x, y.x); y.y = __builtin_fmaf(t, q1.y, y.y);
-            y.z = __builtin_fmaf(t, q1.z, y.z); y.w = __builtin_fmaf(t, q1.w, y.w);
-          }
-          if (s2) {
-            const float t = s2[p];
-            y.x = __builtin_fmaf(t, q2.x, y.x); y.y = __builtin_fmaf(t, q2.y, y.y);
-            y.z = __builtin_fmaf(t, q2.z, y.z); y.w = __builtin_fmaf(t, q2.w, y.w);
-          }
-        }
-        *reinterpret_cast<float4*>(Y + p * ldy + c) = y;
-        const float e[4] = {y.x, y.y, y.z, y.w};
+    for (int r = 0; r < nrows; r += 4) {
+      float4 u[4], v[4];
+      float t1[4], t2[4];
+      int em[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float f = (c + j >= relu_col0) ? fmaxf(e[j], 0.0f) : e[j];
-          a1[j] += f;
-          a2[j] = __builtin_fmaf(f, f, a2[j]);
+      for (int k = 0; k < 4; ++k) {
+        const int rr = min(r + k, nrows - 1);                      // uniform
+        const int a = __builtin_amdgcn_readlane(my_idx, rr);
+        em[k] = __builtin_amdgcn_readlane(my_empty, rr);
+        t1[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_s1), rr));
+        t2[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_s2), rr));
+        const long q = (row0 + wr0 + rr) / K;
+        u[k] = *reinterpret_cast<const float4*>(Ub + static_cast<long>(a) * ldu + cc);
+        v[k] = *reinterpret_cast<const float4*>((em[k] ? V0 : V) + q * ldv + cc);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (r + k < nrows && cok) {                                 // r + k < nrows is uniform
+          float4 y;
+          if (em[k]) {
+            y = v[k];
+          } else {
+            y = make_float4(u[k].x + v[k].x, u[k].y + v[k].y, u[k].z + v[k].z, u[k].w + v[k].w);
+            y.x = __builtin_fmaf(t1[k], q1.x, y.x); y.y = __builtin_fmaf(t1[k], q1.y, y.y);
+            y.z = __builtin_fmaf(t1[k], q1.z, y.z); y.w = __builtin_fmaf(t1[k], q1.w, y.w);
+            y.x = __builtin_fmaf(t2[k], q2.x, y.x); y.y = __builtin_fmaf(t2[k], q2.y, y.y);
+            y.z = __builtin_fmaf(t2[k], q2.z, y.z); y.w = __builtin_fmaf(t2[k], q2.w, y.w);
+          }
+          *reinterpret_cast<float4*>(Y + (row0 + wr0 + r + k) * ldy + c) = y;
+          const float e[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float f = (c + j >= relu_col0) ? fmaxf(e[j], 0.0f) : e[j];
+            a1[j] += f;
+            a2[j] = __builtin_fmaf(f, f, a2[j]);
+          }
         }
       }
     }
@@ -299,13 +332,13 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
         red[wave][4 * lane + j][1] = a2[j];
       }
       __syncthreads();
-      const int cc = c0 + threadIdx.x;
-      if (cc < Cout) {
+      const int cc2 = c0 + threadIdx.x;
+      if (cc2 < Cout) {
         const float t1 = (red[0][threadIdx.x][0] + red[1][threadIdx.x][0]) +
                          (red[2][threadIdx.x][0] + red[3][threadIdx.x][0]);
         const float t2 = (red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) +
                          (red[2][threadIdx.x][1] + red[3][threadIdx.x][1]);
-        float* o = partial + (static_cast<long>(blockIdx.x) * Cout + cc) * 2;
+        float* o = partial + (static_cast<long>(blockIdx.x) * Cout + cc2) * 2;
         o[0] = t1;
         o[1] = t2;
       }
