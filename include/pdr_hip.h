@@ -161,19 +161,30 @@ typedef struct {
   int C;
   int ld;
   int row_div;      /* source row = position / row_div (broadcast over K neighbours) */
+  /* GATHERED source (gV != NULL): the value at position p of batch element b is
+   *     ptr[(b * g_nsrc + gidx[p]) * ld + c]  +  gV[(p / gK) * g_ldv + c]
+   * (neighbour row of a per-source-point table + query row), or gV0[(p / gK) * g_ldv + c] where
+   * gcnt[p / gK] <= 0 (empty ball).  gidx / gcnt / gK live in pdr_layer_in_t.  This is the first
+   * conv of a grouped block (see pdr_gather_add) consumed WITHOUT materialising its output. */
+  const float *gV;
+  const float *gV0;
+  int g_ldv;
+  int g_nsrc;
 } pdr_seg_t;
 
 typedef struct {
   int n_seg;            /* 1..4 channel segments, concatenated in order */
   pdr_seg_t seg[4];
-  const float *scale;   /* (B,Cin) or NULL(=1)  x' = post(pre(x)*scale + shift) + add + radd */
+  const float *scale;   /* (B,Cin) or NULL(=1)  x' = post(pre(x)*scale + shift) + add + residual */
   const float *shift;   /* (B,Cin) or NULL(=0) */
   const float *add;     /* (B,Cin) rows of leading dimension add_ld, or NULL */
-  const float *radd;    /* (P,>=Cin) row-wise residual or NULL */
+  pdr_seg_t rseg;       /* row-wise residual over all Cin channels (ptr NULL = none); may be gathered */
   int add_ld;
-  int radd_ld;
   int pre_relu, post_relu;
   int rows_per_batch;   /* npoint*K: positions per batch element (one GroupNorm instance) */
+  const int *gidx;      /* (P) neighbour index per position, shared by all gathered sources */
+  const int *gcnt;      /* (P / gK) ball counts or NULL */
+  int gK;               /* neighbours per query (power of two) */
 } pdr_layer_in_t;
 
 /* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into
@@ -226,7 +237,8 @@ int pdr_attention_pool(const float *scores, int lds, const float *values, int ld
  * rows): Y[p,:] = U[b, idx[p], :] + V[p / K, :] (+ s1[p] r1[:] + s2[p] r2[:]); where counts[p / K] <= 0
  * (empty ball, subset=False) Y[p,:] = V0[p / K, :].  Replaces QueryAndGroup / group_knn + the first
  * Conv2d (pointnet2_utils.py:368-414, 497-510; pointnet2_modules.py:119-121).  Moments as in
- * pdr_fused_layer with 128-row tiles.  All leading dimensions multiples of 4 floats. */
+ * pdr_fused_layer with 128-row tiles.  All leading dimensions multiples of 4 floats.  Y may be NULL
+ * (moments only): consumers then read the result as a GATHERED source of pdr_fused_layer. */
 int pdr_gather_add(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,
                    const int *idx, const int *counts, const float *s1, const float *r1,
                    const float *s2, const float *r2, int B, int rows_per_batch, int K, int Cout,

@@ -55,14 +55,15 @@ SIGNATURES = {
 
 
 class Seg(_c.Structure):
-    _fields_ = [("ptr", _P), ("C", _I), ("ld", _I), ("row_div", _I)]
+    _fields_ = [("ptr", _P), ("C", _I), ("ld", _I), ("row_div", _I), ("gV", _P), ("gV0", _P), ("g_ldv", _I),
+                ("g_nsrc", _I)]
 
 
 class LayerIn(_c.Structure):
     """pdr_layer_in_t of include/pdr_hip.h."""
-    _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("radd", _P),
-                ("add_ld", _I), ("radd_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I)]
-
+    _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("rseg", Seg),
+                ("add_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I), ("gidx", _P),
+                ("gcnt", _P), ("gK", _I)]
 _lib = None
 
 

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
             y.x = __builtin_fmaf(t2[k], q2.x, y.x); y.y = __builtin_fmaf(t2[k], q2.y, y.y);
             y.z = __builtin_fmaf(t2[k], q2.z, y.z); y.w = __builtin_fmaf(t2[k], q2.w, y.w);
           }
-          *reinterpret_cast<float4*>(Y + (row0 + wr0 + r + k) * ldy + c) = y;
+          if (Y) *reinterpret_cast<float4*>(Y + (row0 + wr0 + r + k) * ldy + c) = y;
           const float e[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -355,12 +355,13 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
                               const float* r1, const float* s2, const float* r2, int B,
                               int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
                               int relu_col0, pdr_stream_t stream) {
-  if (!U || !V || !idx || !Y || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 || n_src <= 0)
+  if (!U || !V || !idx || (!Y && !partial) || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 ||
+      n_src <= 0)
     return PDR_EINVAL;
   if (B == 0) return PDR_OK;
   if (rows_per_batch % K != 0 || (counts && !V0) || (s1 && !r1) || (s2 && !r2)) return PDR_EINVAL;
   const int c4 = (Cout + 3) & ~3;
-  if (ldu % 4 || ldv % 4 || ldy % 4 || ldu < c4 || ldv < c4 || ldy < c4) return PDR_EINVAL;
+  if (ldu % 4 || ldv % 4 || ldu < c4 || ldv < c4 || (Y && (ldy % 4 || ldy < c4))) return PDR_EINVAL;
   const int tpb = (rows_per_batch + 127) / 128;
   hipLaunchKernelGGL(gather_add_kernel, dim3(static_cast<unsigned>(B) * tpb), dim3(256), 0,
                      pdr::as_stream(stream), U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2,

@@ -75,7 +75,7 @@ __device__ __forceinline__ float load_col(const ColSrc& s, long row) {
 // load is `scalar base + 32-bit lane offset`.
 // Pipeline per chunk: global -> registers (prologue applied) is issued BEFORE the MFMAs of the
 // previous chunk, registers -> LDS after them: the loads overlap the matrix pipe.
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC>
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC, bool GATH>
 __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
@@ -117,6 +117,12 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
   // registers of the chunk in flight
   float ra[VEC ? 1 : APT], rr[(RADD && !VEC) ? APT : 1];
   float4 rv[VEC ? APT4 : 1], rrv[(RADD && VEC) ? APT4 : 1];
+  // gathered sources (GATH): second operand (query row) of the chunk / residual in flight, and this
+  // thread's per-tile neighbour indices / empty-ball flags (its rows are the same for every chunk)
+  float4 rv2[GATH ? APT4 : 1], rrv2[(GATH && RADD) ? APT4 : 1];
+  int tidx[GATH ? APT4 : 1], tem[GATH ? APT4 : 1];
+  bool f_g = false;            // chunk in flight comes from a gathered segment
+  const int gshift = GATH ? __builtin_ctz(in.gK) : 0;
   float4 rwv[WPT4];
   float ps[VEC ? 4 : 1], ph[VEC ? 4 : 1], pa[VEC ? 4 : 1];   // per-channel prologue parameters
   float pok[(VEC && RADD) ? 4 : 1];                           // 1 / 0: channel inside the segment
@@ -131,7 +137,15 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     const float* sc_b = in.scale ? in.scale + static_cast<long>(b) * Cin : nullptr;
     const float* sh_b = in.shift ? in.shift + static_cast<long>(b) * Cin : nullptr;
     const float* ad_b = in.add ? in.add + static_cast<long>(b) * in.add_ld : nullptr;
-    const float* rd_b = in.radd ? in.radd + row0 * in.radd_ld : nullptr;
+    const float* rd_b = in.rseg.ptr ? in.rseg.ptr + row0 * in.rseg.ld : nullptr;   // plain residual
+    if constexpr (GATH) {
+#pragma unroll
+      for (int i = 0; i < APT4; ++i) {
+        const int r = min(tid / C4 + VSTEP * i, nvalid - 1);
+        tidx[i] = in.gidx[row0 + r];
+        tem[i] = (in.gcnt && in.gcnt[(row0 + r) >> gshift] <= 0) ? 1 : 0;
+      }
+    }
 
     // fetch(): ONLY address arithmetic + loads -- nothing consumes a loaded value, so no
     // s_waitcnt is emitted and the loads stay in flight across the MFMA loop that follows.
@@ -162,17 +176,41 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
           pa[j] = (ok && ad_b) ? ad_b[cg] : 0.0f;
           if constexpr (RADD) pok[j] = ok ? 1.0f : 0.0f;
         }
-#pragma unroll
-        for (int i = 0; i < APT4; ++i) {
-          // rows beyond nvalid re-read the tile's last row; masked in the epilogue
-          const int r = min(vr0 + VSTEP * i, nvalid - 1);
-          rv[i] = *reinterpret_cast<const float4*>(abase + (r >> shift) * seg.ld + clc);
-        }
-        if constexpr (RADD) {
+        f_g = GATH && seg.gV != nullptr;                             // uniform
+        if (GATH && f_g) {
+          const float* ub = seg.ptr + static_cast<long>(b) * seg.g_nsrc * seg.ld + clc;
 #pragma unroll
           for (int i = 0; i < APT4; ++i) {
             const int r = min(vr0 + VSTEP * i, nvalid - 1);
-            rrv[i] = *reinterpret_cast<const float4*>(rd_b + r * in.radd_ld + cbase + clc);
+            const long q = (row0 + r) >> gshift;
+            rv[i] = *reinterpret_cast<const float4*>(ub + static_cast<long>(tidx[i]) * seg.ld);
+            rv2[i] = *reinterpret_cast<const float4*>((tem[i] ? seg.gV0 : seg.gV) + q * seg.g_ldv + clc);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) {
+            // rows beyond nvalid re-read the tile's last row; masked in the epilogue
+            const int r = min(vr0 + VSTEP * i, nvalid - 1);
+            rv[i] = *reinterpret_cast<const float4*>(abase + (r >> shift) * seg.ld + clc);
+          }
+        }
+        if constexpr (RADD) {
+          if (GATH && in.rseg.gV != nullptr) {
+            const float* ub = in.rseg.ptr + static_cast<long>(b) * in.rseg.g_nsrc * in.rseg.ld + cbase + clc;
+#pragma unroll
+            for (int i = 0; i < APT4; ++i) {
+              const int r = min(vr0 + VSTEP * i, nvalid - 1);
+              const long q = (row0 + r) >> gshift;
+              rrv[i] = *reinterpret_cast<const float4*>(ub + static_cast<long>(tidx[i]) * in.rseg.ld);
+              rrv2[i] = *reinterpret_cast<const float4*>((tem[i] ? in.rseg.gV0 : in.rseg.gV) +
+                                                         q * in.rseg.g_ldv + cbase + clc);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < APT4; ++i) {
+              const int r = min(vr0 + VSTEP * i, nvalid - 1);
+              rrv[i] = *reinterpret_cast<const float4*>(rd_b + r * in.rseg.ld + cbase + clc);
+            }
           }
         }
       } else {
@@ -193,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
 #pragma unroll
           for (int i = 0; i < APT; ++i) {
             const int r = min(ar0 + RSTEP * i, nvalid - 1);
-            rr[i] = rd_b[r * in.radd_ld + cg];
+            rr[i] = rd_b[r * in.rseg.ld + cg];
           }
         }
       }
@@ -215,10 +253,24 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
         const int vc4 = t % C4, vr0 = t / C4;
 #pragma unroll
         for (int i = 0; i < APT4; ++i) {
-          const float x[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+          float x[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+          if constexpr (GATH) {
+            if (f_g) {   // neighbour row + query row; empty ball: the query row alone (V0)
+              const float v2[4] = {rv2[i].x, rv2[i].y, rv2[i].z, rv2[i].w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) x[j] = tem[i] ? v2[j] : x[j] + v2[j];
+            }
+          }
           float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           if constexpr (RADD) {
             q[0] = rrv[i].x; q[1] = rrv[i].y; q[2] = rrv[i].z; q[3] = rrv[i].w;
+            if constexpr (GATH) {
+              if (in.rseg.gV != nullptr) {
+                const float v2[4] = {rrv2[i].x, rrv2[i].y, rrv2[i].z, rrv2[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = tem[i] ? v2[j] : q[j] + v2[j];
+              }
+            }
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -496,7 +548,7 @@ __global__ __launch_bounds__(256) void apply_act_kernel(pdr_layer_in_t in, long 
   v = __builtin_fmaf(v, s, h);
   if (in.post_relu) v = fmaxf(v, 0.0f);
   if (in.add) v += in.add[static_cast<long>(b) * in.add_ld + c];
-  if (in.radd) v += in.radd[row * in.radd_ld + c];
+  if (in.rseg.ptr) v += in.rseg.ptr[row * in.rseg.ld + c];
   out[row * ldo + c] = v;
 }
 
@@ -602,26 +654,51 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   const int nt = static_cast<int>(ntiles);
   // vector (float4) A staging needs every source 16-B aligned with a leading dimension that is a
   // multiple of 4 floats and rows padded to a multiple of 4 channels
-  bool vec = true;
+  auto aligned = [](const float* p, int ld, int C) {
+    return reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld % 4 == 0 && ld >= ((C + 3) & ~3);
+  };
+  bool vec = true, gath = false;
   for (int sg = 0; sg < in->n_seg; ++sg) {
     const pdr_seg_t& g = in->seg[sg];
-    vec = vec && (reinterpret_cast<uintptr_t>(g.ptr) % 16 == 0) && g.ld % 4 == 0 && g.ld >= ((g.C + 3) & ~3);
+    vec = vec && aligned(g.ptr, g.ld, g.C);
+    if (g.gV) {
+      gath = true;
+      vec = vec && aligned(g.gV, g.g_ldv, g.C) && (!g.gV0 || aligned(g.gV0, g.g_ldv, g.C));
+      if (g.row_div != 1 || g.g_nsrc <= 0) return PDR_EINVAL;
+    }
   }
-  if (in->radd)
-    vec = vec && in->n_seg == 1 && (reinterpret_cast<uintptr_t>(in->radd) % 16 == 0) && in->radd_ld % 4 == 0 &&
-          in->radd_ld >= ((Cin + 3) & ~3);
-#define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC)                                               \
-  hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC>), grid, dim3(256), 0, s, *in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt)
-#define PDR_LAUNCH(RT, CT, WR, WC, KC)                          \
-  do {                                                          \
-    if (in->radd) {                                             \
-      if (vec) PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, true);    \
-      else PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, false);       \
-    } else {                                                    \
-      if (vec) PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, true);   \
-      else PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, false);      \
-    }                                                           \
+  const bool radd = in->rseg.ptr != nullptr;
+  if (radd) {
+    vec = vec && in->n_seg == 1 && aligned(in->rseg.ptr, in->rseg.ld, Cin);
+    if (in->rseg.gV) {
+      gath = true;
+      vec = vec && aligned(in->rseg.gV, in->rseg.g_ldv, Cin) &&
+            (!in->rseg.gV0 || aligned(in->rseg.gV0, in->rseg.g_ldv, Cin));
+    }
+  }
+  if (gath) {
+    // gathered sources exist only in the vector path; one shared index array, K a power of two that
+    // divides the row tile so that a tile starts on a query boundary
+    if (!vec || !in->gidx || in->gK <= 0 || (in->gK & (in->gK - 1)) || in->rows_per_batch % in->gK != 0 ||
+        t.tm % in->gK != 0)
+      return PDR_EUNSUPPORTED;
+    for (int sg = 0; sg < in->n_seg; ++sg)
+      if (in->seg[sg].gV && in->gcnt && !in->seg[sg].gV0) return PDR_EINVAL;
+  }
+#define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC, GATH)                                            \
+  hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC, GATH>), grid, dim3(256), 0, s, \
+                     *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt)
+#define PDR_LAUNCH(RT, CT, WR, WC, KC)                                \
+  do {                                                                \
+    if (radd) {                                                       \
+      if (gath) PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, true, true);   \
+      else if (vec) PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, true, false); \
+      else PDR_LAUNCH_V(RT, CT, WR, WC, KC, true, false, false);      \
+    } else {                                                          \
+      if (gath) PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, true, true);  \
+      else if (vec) PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, true, false); \
+      else PDR_LAUNCH_V(RT, CT, WR, WC, KC, false, false, false);     \
+    }                                                                 \
   } while (0)
   switch (t.id) {
     case 0: PDR_LAUNCH(2, 1, 4, 1, 16); break;
@@ -671,10 +748,12 @@ extern "C" int pdr_apply_act(const pdr_layer_in_t* in, long P, int C, float* out
                              pdr_stream_t stream) {
   if (!in || !out || P < 0 || C <= 0 || in->n_seg < 1 || in->n_seg > 4 || in->rows_per_batch <= 0)
     return PDR_EINVAL;
+  if (in->rseg.gV) return PDR_EUNSUPPORTED;   // gathered sources: pdr_fused_layer only
   if (P == 0) return PDR_OK;
   int ctot = 0;
   for (int s = 0; s < in->n_seg; ++s) {
     if (in->seg[s].row_div < 1 || (in->seg[s].row_div & (in->seg[s].row_div - 1))) return PDR_EUNSUPPORTED;
+    if (in->seg[s].gV) return PDR_EUNSUPPORTED;
     ctot += in->seg[s].C;
   }
   if (ctot != C) return PDR_EINVAL;

@@ -38,6 +38,13 @@ from .models.pointnet2_ssg_sem import calc_t_emb
 # First conv of every grouped block through per-point U / V tables + pdr_gather_add instead of a GEMM
 # over the materialised grouped tensor (see SplitFirstConv).  False = reference-shaped evaluation.
 USE_SPLIT_FIRST = True
+# Optionally that first conv's (P x Cout) output is never written: its three consumers (second MLP
+# conv, attention key, residual) gather U[idx] + V through the A-loader of pdr_fused_layer (ball-query
+# blocks only; the kNN form carries two extra per-position terms and is always materialised).
+# Measured on MI355X (B=32): 17.3 ms/step virtual vs 14.0 ms/step materialised -- the two dependent
+# 64-B gathers per row cost more than the HBM round trip they save -- so it is OFF; kept (and tested)
+# as the starting point for an index-prefetching variant.
+USE_VIRTUAL_FIRST = False
 
 
 def _stream():
@@ -48,31 +55,72 @@ def _ptr(t, offset=0):
     return t.data_ptr() + 4 * offset
 
 
+def _fill_seg(cseg, seg):
+    """seg = (tensor, offset_floats, C, ld, row_div[, gather]) -> pdr_seg_t."""
+    t, off, C, ld, div = seg[:5]
+    cseg.ptr, cseg.C, cseg.ld, cseg.row_div = _ptr(t, off), C, ld, div
+    g = seg[5] if len(seg) > 5 else None
+    if g is not None:
+        cseg.gV = _ptr(g["V"][0], g["V"][1])
+        cseg.gV0 = _ptr(g["V0"][0], g["V0"][1]) if g.get("V0") is not None else None
+        cseg.g_ldv, cseg.g_nsrc = g["ldv"], g["nsrc"]
+
+
 class Act:
     """A lazily-evaluated activation: channel segments + the prologue the consumer applies."""
 
     def __init__(self, segs, P, B, rows_per_batch, scale=None, shift=None, add=None, add_ld=0, radd=None,
                  pre_relu=False, post_relu=False):
-        self.segs = segs          # [(tensor, offset_floats, C, ld, row_div)]
+        self.segs = segs          # [(tensor, offset_floats, C, ld, row_div[, gather dict])]
         self.P, self.B, self.rpb = P, B, rows_per_batch
         self.scale, self.shift, self.add, self.add_ld = scale, shift, add, add_ld
-        self.radd = radd          # (tensor, offset_floats, ld) or None
+        self.radd = radd          # a segment tuple covering all channels, or None
         self.pre_relu, self.post_relu = pre_relu, post_relu
         self.C = sum(s[2] for s in segs)
+        self.gidx = self.gcnt = None   # shared neighbour index / ball counts of gathered segments
+        self.gK = 0
 
     def struct(self):
         li = _lib.LayerIn()
         li.n_seg = len(self.segs)
-        for i, (t, off, C, ld, div) in enumerate(self.segs):
-            li.seg[i].ptr, li.seg[i].C, li.seg[i].ld, li.seg[i].row_div = _ptr(t, off), C, ld, div
+        for i, seg in enumerate(self.segs):
+            _fill_seg(li.seg[i], seg)
         li.scale = self.scale.data_ptr() if self.scale is not None else None
         li.shift = self.shift.data_ptr() if self.shift is not None else None
         li.add = self.add.data_ptr() if self.add is not None else None
         li.add_ld = self.add_ld if self.add is not None else 0
         if self.radd is not None:
-            li.radd, li.radd_ld = _ptr(self.radd[0], self.radd[1]), self.radd[2]
+            _fill_seg(li.rseg, self.radd)
         li.pre_relu, li.post_relu, li.rows_per_batch = int(self.pre_relu), int(self.post_relu), self.rpb
+        if self.gidx is not None:
+            li.gidx = self.gidx.data_ptr()
+            li.gcnt = self.gcnt.data_ptr() if self.gcnt is not None else None
+            li.gK = self.gK
         return li
+
+
+class FirstOut:
+    """Output of a block's first conv: a materialised (P, ld) tensor, or VIRTUAL = per-source-point table
+    U, per-query tables V / V0 and the neighbour index, read by consumers as a gathered source."""
+
+    def __init__(self, Y=None, U=None, V=None, V0=None, idx=None, counts=None, K=0, nsrc=0):
+        self.Y, self.U, self.V, self.V0, self.idx, self.counts, self.K, self.nsrc = Y, U, V, V0, idx, counts, K, nsrc
+
+    @property
+    def virtual(self):
+        return self.Y is None
+
+    def seg(self, col0, C):
+        if not self.virtual:
+            return (self.Y, col0, C, self.Y.shape[1], 1)
+        g = {"V": (self.V, col0), "V0": (self.V0, col0) if self.V0 is not None else None,
+             "ldv": self.V.shape[1], "nsrc": self.nsrc}
+        return (self.U, col0, C, self.U.shape[1], 1, g)
+
+    def attach(self, act):
+        if self.virtual:
+            act.gidx, act.gcnt, act.gK = self.idx, self.counts, self.K
+        return act
 
 
 def _pad4(c):
@@ -254,10 +302,10 @@ class FusedMlp:
         return self.after_first(Y1, part1, tpb1, x.P, x.B, x.rpb, bank, x)
 
     def after_first(self, Y1, part1, tpb1, P, B, rpb, bank, x=None):
-        """Everything behind the first GEMM, given its output (however it was produced)."""
-        Y, part, tpb = Y1, part1, tpb1
-        ld = Y.shape[1]
-        cur = Act([(Y, 0, self.C1, ld, 1)], P, B, rpb)
+        """Everything behind the first conv, given its output `Y1` (a tensor or a FirstOut)."""
+        first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
+        part, tpb = part1, tpb1
+        cur = first.attach(Act([first.seg(0, self.C1)], P, B, rpb))
         for i, norm in enumerate(self.norms):
             C = cur.C
             scale, shift = norm.fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
@@ -270,15 +318,14 @@ class FusedMlp:
                 cur = Act([(Y, 0, self.rest[i].Cout, Y.shape[1], 1)], P, B, rpb)
         if self.has_res:
             if self.res_col0 is not None:
-                cur.radd = (Y1, self.res_col0, ld)
+                cur.radd = first.seg(self.res_col0, self.Clast)
+                first.attach(cur)
             else:
                 if x is None or len(x.segs) != 1 or x.scale is not None or x.pre_relu or x.post_relu or \
                         x.add is not None:
                     raise NotImplementedError("identity residual over a composite input")
-                t, off, C, ldx, div = x.segs[0]
-                assert div == 1
-                cur.radd = (t, off, ldx)
-        return cur, Y1, part1, tpb1
+                cur.radd = x.segs[0]
+        return cur, first, part1, tpb1
 
 
 class FusedAttention:
@@ -304,13 +351,13 @@ class FusedAttention:
         """query: (B*npoint, Cq) tensor; h: Act (value input); key = Y1[:, key_col0:key_col0+C2]."""
         lib = _lib.load()
         P = B * npoint * K
-        ld1 = Y1.shape[1]
+        first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
         q, qpart, qtpb = run_layer(plain(query, B, npoint), self.q, stats=True, relu_col0=0)
         Ct = self.C1 + self.C2
         s, t = self.n1.fold([(qpart, 0, self.C1, qtpb, float(K)), (part1, key_col0, self.C2, tpb1, 1.0)], B, Ct,
                             npoint * K)
-        a = Act([(q, 0, self.C1, q.shape[1], K), (Y1, key_col0, self.C2, ld1, 1)], P, B, npoint * K, scale=s,
-                shift=t, pre_relu=True)
+        a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B, npoint * K,
+                             scale=s, shift=t, pre_relu=True))
         S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
         scores, _, _ = run_layer(Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t,
@@ -374,8 +421,10 @@ class SplitFirstConv:
             self.V = _RawConv(W_x - W_rel, bias, Cout)
             self.V0 = None
 
-    def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None):
-        """-> (Y1 (B*m*K, ld), partial, tiles_per_batch)."""
+    def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
+                 virtual=False):
+        """-> (Y1, partial, tiles_per_batch).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
+        consumers read as a gathered source (only the GroupNorm moments are computed here)."""
         lib = _lib.load()
         B, n, Cs = src_feats_cl.shape
         m = query_xyz.shape[1]
@@ -390,14 +439,18 @@ class SplitFirstConv:
         ld = U.shape[1]
         rpb = m * K
         tpb = (rpb + 127) // 128
-        Y = torch.empty((B * rpb, ld), dtype=torch.float32, device=U.device)
+        virtual = virtual and s1 is None and s2 is None and (K & (K - 1)) == 0 and 128 % K == 0
+        Y = None if virtual else torch.empty((B * rpb, ld), dtype=torch.float32, device=U.device)
         partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
         _lib.check(lib.pdr_gather_add(
             U.data_ptr(), ld, n, V.data_ptr(), V0.data_ptr() if V0 is not None else None, ld, idx32.data_ptr(),
             counts.data_ptr() if counts is not None else None,
             s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
             s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
-            B, rpb, K, self.Cout, Y.data_ptr(), ld, partial.data_ptr(), relu_col0, _stream()), "gather_add")
+            B, rpb, K, self.Cout, Y.data_ptr() if Y is not None else None, ld, partial.data_ptr(), relu_col0,
+            _stream()), "gather_add")
+        if virtual:
+            return FirstOut(U=U, V=V, V0=V0, idx=idx32, counts=counts, K=K, nsrc=n), partial, tpb
         return Y, partial, tpb
 
 
@@ -446,7 +499,7 @@ class FusedGroupedBlock:
                 self.split = SplitFirstConv(self.mlp.first, src_feats_cl.shape[2], 'ball', self.with_abs,
                                             self.with_centre)
             Y1, part1, tpb1 = self.split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
-                                         self.mlp.extra_col0)
+                                         self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST)
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
         else:
             G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,

@@ -47,7 +47,7 @@ def test_fused_layer_matches_torch(cuda, P, Cin, Cout, rpb):
     bias = torch.randn(Cout, generator=g).to(cuda)
     segs = [(q, 0, c1, c1, K)] + ([(k, 3, Cin - c1, Cin - c1 + 5, 1)] if Cin > c1 else [])
     for pre, post in ((False, True), (True, False)):
-        act = FN.Act(segs, P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin, radd=(radd, 1, Cin + 2),
+        act = FN.Act(segs, P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin, radd=(radd, 1, Cin, Cin + 2, 1),
                      pre_relu=pre, post_relu=post)
         conv = _conv(W, bias)
         Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=Cout // 2)
@@ -100,11 +100,12 @@ def _cached_eps(net, fused, x, cond, ts, label):
     return got, ref
 
 
-@pytest.mark.parametrize("split_first", [True, False])
+@pytest.mark.parametrize("split_first", ["virtual", "materialised", False])
 def test_fused_network_small_config(cuda, split_first, monkeypatch):
     """split_first=True: first conv of each grouped block via per-point U/V tables + gather_add;
     False: GEMM over the materialised grouped tensor (group_build / knn_build).  Both must match torch."""
-    monkeypatch.setattr(FN, "USE_SPLIT_FIRST", split_first)
+    monkeypatch.setattr(FN, "USE_SPLIT_FIRST", bool(split_first))
+    monkeypatch.setattr(FN, "USE_VIRTUAL_FIRST", split_first == "virtual")
     net, fused = _pair(small_fused_config(), 21, cuda)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 256, 3, generator=g).to(cuda)
@@ -168,7 +169,7 @@ def test_fused_layer_vector_staging(cuda, P, Cin, Cout, rpb):
     bidx = torch.arange(P, device=cuda) // rpb
     for use_radd in (False, True):
         act = FN.Act([(x, 0, Cin, ld, 1)], P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin,
-                     radd=(radd, 0, ld) if use_radd else None, post_relu=True)
+                     radd=(radd, 0, Cin, ld, 1) if use_radd else None, post_relu=True)
         Y, part, tpb = FN.run_layer(act, conv, stats=True)
         ref = (x[:, :Cin] * scale[bidx] + shift[bidx]).relu() + add[bidx]
         if use_radd:

@@ -35,7 +35,7 @@ def dominant_kernel_roofline(sampler, reps=3):
         e0.record()
         out = original(act, conv, stats, relu_col0)
         e1.record()
-        seg_bytes = sum(4 * C * act.P // div for (_, _, C, _, div) in act.segs)
+        seg_bytes = sum(4 * sg[2] * act.P // sg[4] for sg in act.segs)
         records.append((e0, e1, 2.0 * act.P * conv.Cin * conv.Cout, seg_bytes + 4.0 * act.P * conv.Cout))
         return out
 

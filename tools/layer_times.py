@@ -33,8 +33,8 @@ def instrument(records):
     def layer_meta(a, k, out):
         act, conv = a[0], a[1]
         src_bytes = 0
-        for (t, off, C, ld, div) in act.segs:
-            src_bytes += 4 * C * act.P // div
+        for sg in act.segs:
+            src_bytes += 4 * sg[2] * act.P // sg[4]
         if act.radd is not None:
             src_bytes += 4 * act.C * act.P
         return dict(P=act.P, Cin=conv.Cin, Cout=conv.Cout, bytes=src_bytes + 4 * conv.Cout * act.P,
@@ -47,6 +47,11 @@ def instrument(records):
     FN.materialize = wrap("apply_act", FN.materialize,
                           lambda a, k, out: dict(P=out.shape[0], Cin=0, Cout=out.shape[1], bytes=8 * out.numel(),
                                                  flops=0))
+    split_call = FN.SplitFirstConv.__call__
+    FN.SplitFirstConv.__call__ = wrap(
+        "split_first", split_call,
+        lambda a, k, out: dict(P=out[0].shape[0], Cin=a[1].shape[2] + 9, Cout=a[0].Cout,
+                               bytes=8 * out[0].shape[0] * a[0].Cout, flops=0))
     fold = FN.Norm.fold
     FN.Norm.fold = wrap("gn_fold", fold, lambda a, k, out: dict(P=0, Cin=0, Cout=out[0].shape[1], bytes=0, flops=0))
 
