@@ -185,6 +185,12 @@ typedef struct {
   const int *gidx;      /* (P) neighbour index per position, shared by all gathered sources */
   const int *gcnt;      /* (P / gK) ball counts or NULL */
   int gK;               /* neighbours per query (power of two) */
+  int ss_ld;            /* leading dimension of scale / shift rows (0 = Cin) */
+  /* OUTPUT-side broadcast add: y[p, :] += oadd[(p / oadd_div) * oadd_ld + :] before the moments.
+   * Used for the query half of the attention score conv: conv([q.expand(K) | k]) = conv_k(k) + Z[query] */
+  const float *oadd;
+  int oadd_ld;
+  int oadd_div;         /* power of two */
 } pdr_layer_in_t;
 
 /* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into

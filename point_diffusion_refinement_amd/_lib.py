@@ -63,7 +63,7 @@ class LayerIn(_c.Structure):
     """pdr_layer_in_t of include/pdr_hip.h."""
     _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("rseg", Seg),
                 ("add_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I), ("gidx", _P),
-                ("gcnt", _P), ("gK", _I)]
+                ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I)]
 _lib = None
 
 

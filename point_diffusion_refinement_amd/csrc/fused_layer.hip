@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     const int b = tile / tpb, tb = tile - b * tpb;
     const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
     const int nvalid = min(TM, rpb - tb * TM);
-    const float* sc_b = in.scale ? in.scale + static_cast<long>(b) * Cin : nullptr;
-    const float* sh_b = in.shift ? in.shift + static_cast<long>(b) * Cin : nullptr;
+    const int ss_ld = in.ss_ld > 0 ? in.ss_ld : Cin;
+    const float* sc_b = in.scale ? in.scale + static_cast<long>(b) * ss_ld : nullptr;
+    const float* sh_b = in.shift ? in.shift + static_cast<long>(b) * ss_ld : nullptr;
     const float* ad_b = in.add ? in.add + static_cast<long>(b) * in.add_ld : nullptr;
     const float* rd_b = in.rseg.ptr ? in.rseg.ptr + row0 * in.rseg.ld : nullptr;   // plain residual
     if constexpr (GATH) {
@@ -366,6 +367,19 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
       const bool relu_stat = col >= relu_col0;
       float s1 = 0.0f, s2 = 0.0f;
       float* ybase = Y + row0 * ldy + col;
+      if (colok && in.oadd) {
+        // per-query term of a split conv (one row of `oadd` per oadd_div positions)
+        const int osh = __builtin_ctz(in.oadd_div);
+        const float* ob = in.oadd + col;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = min((wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, nvalid - 1);
+            acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
+          }
+        }
+      }
       if (colok) {
         if (rows_full) {
 #pragma unroll
@@ -543,8 +557,9 @@ __global__ __launch_bounds__(256) void apply_act_kernel(pdr_layer_in_t in, long 
   const int b = static_cast<int>(row / in.rows_per_batch);
   float v = load_col(resolve_col(in, c), row);
   if (in.pre_relu) v = fmaxf(v, 0.0f);
-  const float s = in.scale ? in.scale[static_cast<long>(b) * C + c] : 1.0f;
-  const float h = in.shift ? in.shift[static_cast<long>(b) * C + c] : 0.0f;
+  const int ss_ld = in.ss_ld > 0 ? in.ss_ld : C;
+  const float s = in.scale ? in.scale[static_cast<long>(b) * ss_ld + c] : 1.0f;
+  const float h = in.shift ? in.shift[static_cast<long>(b) * ss_ld + c] : 0.0f;
   v = __builtin_fmaf(v, s, h);
   if (in.post_relu) v = fmaxf(v, 0.0f);
   if (in.add) v += in.add[static_cast<long>(b) * in.add_ld + c];
@@ -636,6 +651,9 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     ctot += in->seg[s].C;
   }
   if (ctot != Cin || in->rows_per_batch <= 0 || P % in->rows_per_batch != 0) return PDR_EINVAL;
+  if (in->oadd && (in->oadd_div < 1 || (in->oadd_div & (in->oadd_div - 1)) || in->oadd_ld < Cout))
+    return PDR_EINVAL;
+  if (in->ss_ld != 0 && in->ss_ld < Cin) return PDR_EINVAL;
   const TileCfg t = pick_tile(in->rows_per_batch, Cout);
   for (int sg = 0; sg < in->n_seg; ++sg) {
     // every tile must start on a multiple of the broadcast divisor

@@ -38,6 +38,8 @@ from .models.pointnet2_ssg_sem import calc_t_emb
 # First conv of every grouped block through per-point U / V tables + pdr_gather_add instead of a GEMM
 # over the materialised grouped tensor (see SplitFirstConv).  False = reference-shaped evaluation.
 USE_SPLIT_FIRST = True
+# Attention score conv over [q.expand(K) | k]: evaluate the query half once per query (see FusedAttention)
+SPLIT_QUERY_CONV = True
 # Optionally that first conv's (P x Cout) output is never written: its three consumers (second MLP
 # conv, attention key, residual) gather U[idx] + V through the A-loader of pdr_fused_layer (ball-query
 # blocks only; the kNN form carries two extra per-position terms and is always materialised).
@@ -79,6 +81,8 @@ class Act:
         self.C = sum(s[2] for s in segs)
         self.gidx = self.gcnt = None   # shared neighbour index / ball counts of gathered segments
         self.gK = 0
+        self.ss_ld = 0                 # leading dimension of scale / shift (0 = C)
+        self.oadd = None               # (tensor (rows, ld), div): output-side per-query add
 
     def struct(self):
         li = _lib.LayerIn()
@@ -92,6 +96,9 @@ class Act:
         if self.radd is not None:
             _fill_seg(li.rseg, self.radd)
         li.pre_relu, li.post_relu, li.rows_per_batch = int(self.pre_relu), int(self.post_relu), self.rpb
+        li.ss_ld = self.ss_ld
+        if self.oadd is not None:
+            li.oadd, li.oadd_ld, li.oadd_div = self.oadd[0].data_ptr(), self.oadd[0].shape[1], self.oadd[1]
         if self.gidx is not None:
             li.gidx = self.gidx.data_ptr()
             li.gcnt = self.gcnt.data_ptr() if self.gcnt is not None else None
@@ -340,6 +347,12 @@ class FusedAttention:
         if len(wc) != 6:
             raise NotImplementedError("attention score net without GroupNorm (attention_bn=False)")
         self.n1, self.w1, self.n2, self.w2 = Norm(wc[1]), Conv([wc[2]]), Norm(wc[4]), Conv([wc[5]])
+        # conv([q.expand(K) | k]) = conv_k(k) + conv_q(q): the query half is evaluated once per QUERY
+        # (K times fewer flops) and enters the per-position GEMM as an output-side broadcast add
+        c1 = att.feat_conv.weight.shape[0]
+        zero_b = torch.zeros_like(self.w1.bias)
+        self.w1_q = _RawConv(self.w1.Wt[:c1], self.w1.bias, self.w1.Cout)
+        self.w1_k = _RawConv(self.w1.Wt[c1:], zero_b, self.w1.Cout)
         fo = list(att.feat_out_conv)
         self.v = Conv([fo[0]])
         self.v_norm = Norm(fo[1]) if len(fo) > 1 and isinstance(fo[1], MyGroupNorm) else None
@@ -356,9 +369,19 @@ class FusedAttention:
         Ct = self.C1 + self.C2
         s, t = self.n1.fold([(qpart, 0, self.C1, qtpb, float(K)), (part1, key_col0, self.C2, tpb1, 1.0)], B, Ct,
                             npoint * K)
-        a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B, npoint * K,
-                             scale=s, shift=t, pre_relu=True))
-        S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
+        if SPLIT_QUERY_CONV and (K & (K - 1)) == 0:
+            zq = Act([(q, 0, self.C1, q.shape[1], 1)], B * npoint, B, npoint, scale=s, shift=t, pre_relu=True)
+            zq.ss_ld = Ct
+            Z, _, _ = run_layer(zq, self.w1_q)
+            a = first.attach(Act([first.seg(key_col0, self.C2)], P, B, npoint * K, scale=s[:, self.C1:],
+                                 shift=t[:, self.C1:], pre_relu=True))
+            a.ss_ld = Ct
+            a.oadd = (Z, K)
+            S1, p1, tp = run_layer(a, self.w1_k, stats=True, relu_col0=0)
+        else:
+            a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B,
+                                 npoint * K, scale=s, shift=t, pre_relu=True))
+            S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
         scores, _, _ = run_layer(Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t,
                                      pre_relu=True), self.w2)
