@@ -207,6 +207,14 @@ int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,
                     int relu_col0, pdr_stream_t stream);
+/* pdr_fused_layer whose output (the attention scores, D channels) is consumed in the epilogue:
+ * out[q,:] = sum_k softmax_k(mask(scores))[k,:] * act(values[q*K+k,:]*vscale + vshift); the (P x D)
+ * score tensor is never written.  K in {8,16,32}; counts (P/K) or NULL = all neighbours valid.
+ * = weight_conv's last Conv2d + mask + F.softmax + weighted sum (attention.py:83-96). */
+int pdr_fused_layer_pool(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
+                         const float *bias, int D, const float *values, int ldv, const float *vscale,
+                         const float *vshift, int v_relu, const int *counts, int K, float *out,
+                         int ldo, pdr_stream_t stream);
 /* chan_stats[b, coff+c] (double sum, double sumsq) = mult * sum over tiles of batch b;
  * `partial` points at the first of C columns inside rows of ldp columns */
 int pdr_gn_reduce(const float *partial, int ldp, int B, int tiles_per_batch, int C, double mult,

@@ -75,11 +75,23 @@ __device__ __forceinline__ float load_col(const ColSrc& s, long row) {
 // load is `scalar base + 32-bit lane offset`.
 // Pipeline per chunk: global -> registers (prologue applied) is issued BEFORE the MFMAs of the
 // previous chunk, registers -> LDS after them: the loads overlap the matrix pipe.
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC, bool GATH>
+// POOL epilogue: the GEMM output is the attention SCORE of every (query, neighbour) position; instead
+// of being stored it is masked by the ball count, soft-maxed over the K neighbours of its query and
+// used to weight the value rows (attention.py:83-96) -- the (P x D) score tensor never exists.
+struct PoolArgs {
+  const float* values;   // (P, ldv) value conv output (pre-GroupNorm)
+  const float* vscale;   // (B, D) folded GroupNorm of the values, or NULL
+  const float* vshift;
+  const int* counts;     // (P / K) valid neighbours per query, or NULL = all
+  float* out;            // (P / K, ldo)
+  int ldv, ldo, K, v_relu;
+};
+
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC, bool GATH, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int n_row_tiles) {
+    float* __restrict__ partial, int relu_col0, int n_row_tiles, PoolArgs pool = PoolArgs()) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
   // scalar A path: thread -> (column ac, rows ar0 + RSTEP i)
@@ -358,6 +370,64 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     int il_e = il;
     asm volatile("" : "+v"(il_e));
     const bool rows_full = nvalid == TM;   // uniform
+    if constexpr (POOL) {
+      // a 32-row MFMA tile holds 32 / K whole queries (K in {8, 16, 32}); for a fixed column a
+      // query's K rows sit in registers {r : (r >> 2) / (K / 8) == g} of both lane halves
+      const int K = pool.K;
+      const int gsz = K >> 3;                 // 8-row register groups per query
+      const int ksh = __builtin_ctz(K);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int col = n0 + (wc * CT + j) * 32 + il_e;
+        const bool colok = col < Cout;
+        const int cc = colok ? col : 0;
+        const float bv = bias_r[j];
+        const float vs = pool.vscale ? pool.vscale[static_cast<long>(b) * Cout + cc] : 1.0f;
+        const float vh = pool.vshift ? pool.vshift[static_cast<long>(b) * Cout + cc] : 0.0f;
+        const float lo = pool.v_relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const int rbase = (wr * RT + i) * 32;
+          if (rbase >= nvalid) continue;        // uniform (tiles end on query boundaries)
+          float val[16], sc[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = rbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const long p = row0 + rl;
+            int cnt = K;
+            if (pool.counts) {
+              cnt = pool.counts[p >> ksh];
+              cnt = cnt < 1 ? 1 : cnt;
+            }
+            const int kk = rl & (K - 1);
+            sc[r] = kk < cnt ? acc[i][j][r] + bv : -1e9f;
+            val[r] = fmaxf(__builtin_fmaf(pool.values[p * pool.ldv + cc], vs, vh), lo);
+          }
+          for (int g = 0; g < 4; g += gsz) {      // uniform trip count
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((r >> 2) >= g && (r >> 2) < g + gsz) m = fmaxf(m, sc[r]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.0f, a = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((r >> 2) >= g && (r >> 2) < g + gsz) {
+                const float w = expf(sc[r] - m);
+                l += w;
+                a = __builtin_fmaf(val[r], w, a);
+              }
+            l += __shfl_xor(l, 32, 64);
+            a += __shfl_xor(a, 32, 64);
+            if (hi == 0 && colok) {
+              const long q = (row0 + rbase + 8 * g) >> ksh;
+              pool.out[q * pool.ldo + col] = a / l;
+            }
+          }
+        }
+      }
+      continue;   // next row tile
+    }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
       const int cl = (wc * CT + j) * 32 + il_e;
@@ -729,6 +799,58 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   }
 #undef PDR_LAUNCH
 #undef PDR_LAUNCH_V
+  return pdr::check_launch();
+}
+
+// scores = prologue(X) . Wt + bias are consumed by the POOL epilogue:
+//   out[q, :] = sum_k softmax_k(mask(scores))[k, :] * act(values[q K + k, :] * vscale + vshift)
+// K in {8, 16, 32}; Cout = D (channels of scores, values and out).
+extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
+                                    const float* bias, int D, const float* values, int ldv,
+                                    const float* vscale, const float* vshift, int v_relu,
+                                    const int* counts, int K, float* out, int ldo,
+                                    pdr_stream_t stream) {
+  if (!in || !Wt || !values || !out || P <= 0 || Cin <= 0 || D <= 0 || in->n_seg < 1 || in->n_seg > 4 ||
+      ldw < D || ldw % 4 != 0 || reinterpret_cast<uintptr_t>(Wt) % 16 != 0 || ldv < D || ldo < D)
+    return PDR_EINVAL;
+  if (!(K == 8 || K == 16 || K == 32)) return PDR_EUNSUPPORTED;
+  if (in->rseg.ptr || in->oadd) return PDR_EUNSUPPORTED;
+  int ctot = 0;
+  bool vec = true;
+  for (int s = 0; s < in->n_seg; ++s) {
+    const pdr_seg_t& g = in->seg[s];
+    if (!g.ptr || g.C <= 0 || g.row_div != 1 || g.gV) return PDR_EUNSUPPORTED;
+    vec = vec && reinterpret_cast<uintptr_t>(g.ptr) % 16 == 0 && g.ld % 4 == 0 && g.ld >= ((g.C + 3) & ~3);
+    ctot += g.C;
+  }
+  if (ctot != Cin || in->rows_per_batch <= 0 || P % in->rows_per_batch != 0 || in->rows_per_batch % 32 != 0)
+    return PDR_EINVAL;
+  if (!vec) return PDR_EUNSUPPORTED;
+  const TileCfg t = pick_tile(in->rows_per_batch, D);
+  hipStream_t s = pdr::as_stream(stream);
+  const long nb = P / in->rows_per_batch;
+  const long ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
+  const int ncol = (D + t.tn - 1) / t.tn;
+  long gx = ntiles;
+  const long cap = (256L * 6 + ncol - 1) / ncol;
+  if (gx > cap) gx = cap;
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
+  const int nt = static_cast<int>(ntiles);
+  PoolArgs pa{values, vscale, vshift, counts, out, ldv, ldo, K, v_relu};
+#define PDR_LAUNCH_P(RT, CT, WR, WC, KC)                                                              \
+  hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false, true, false, true>), grid, dim3(256), \
+                     0, s, *in, Cin, Wt, ldw, bias, D, static_cast<float*>(nullptr), 0,                   \
+                     static_cast<float*>(nullptr), D, nt, pa)
+  switch (t.id) {
+    case 0: PDR_LAUNCH_P(2, 1, 4, 1, 16); break;
+    case 1: PDR_LAUNCH_P(2, 2, 4, 1, 16); break;
+    case 2: PDR_LAUNCH_P(1, 3, 4, 1, 32); break;
+    case 3: PDR_LAUNCH_P(1, 5, 4, 1, 32); break;
+    case 4: PDR_LAUNCH_P(2, 2, 2, 2, 32); break;
+    case 5: PDR_LAUNCH_P(1, 2, 2, 2, 32); break;
+    default: PDR_LAUNCH_P(1, 1, 1, 4, 32); break;
+  }
+#undef PDR_LAUNCH_P
   return pdr::check_launch();
 }
 

@@ -40,6 +40,10 @@ from .models.pointnet2_ssg_sem import calc_t_emb
 USE_SPLIT_FIRST = True
 # Attention score conv over [q.expand(K) | k]: evaluate the query half once per query (see FusedAttention)
 SPLIT_QUERY_CONV = True
+# Last attention score conv + mask + softmax + weighted sum in one kernel (scores never written).
+# Measured: 14.0 ms/step fused vs 13.5 ms/step separate -- the MFMA accumulator layout forces 4-byte
+# value loads in the epilogue, which costs more than the score round trip saves.  OFF; kept and tested.
+FUSE_SCORE_POOL = False
 # Optionally that first conv's (P x Cout) output is never written: its three consumers (second MLP
 # conv, attention key, residual) gather U[idx] + V through the A-loader of pdr_fused_layer (ball-query
 # blocks only; the kNN form carries two extra per-position terms and is always materialised).
@@ -383,18 +387,27 @@ class FusedAttention:
                                  npoint * K, scale=s, shift=t, pre_relu=True))
             S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
-        scores, _, _ = run_layer(Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t,
-                                     pre_relu=True), self.w2)
+        score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
         V, pv, tpv = run_layer(h, self.v, stats=self.v_norm is not None)
         vs = vt = None
         if self.v_norm is not None:
             vs, vt = self.v_norm.fold([(pv, 0, self.D, tpv, 1.0)], B, self.D, npoint * K)
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
-        _lib.check(lib.pdr_attention_pool(scores.data_ptr(), scores.shape[1], V.data_ptr(), V.shape[1],
-                                          vs.data_ptr() if vs is not None else None,
-                                          vt.data_ptr() if vt is not None else None, int(self.v_relu),
-                                          counts.data_ptr() if counts is not None else None, B, npoint, K, self.D,
-                                          out.data_ptr(), _stream()), "attention_pool")
+        cptr = counts.data_ptr() if counts is not None else None
+        vsp, vtp = (vs.data_ptr(), vt.data_ptr()) if vs is not None else (None, None)
+        if FUSE_SCORE_POOL and K in (8, 16, 32) and (npoint * K) % 32 == 0 and self.D % 4 == 0:
+            # last score conv + mask + softmax over K + weighted sum in ONE kernel: scores stay in the
+            # MFMA accumulators
+            li = score_in.struct()
+            _lib.check(lib.pdr_fused_layer_pool(ctypes.byref(li), P, self.w2.Cin, self.w2.Wt.data_ptr(), self.w2.ldw,
+                                                self.w2.bias.data_ptr(), self.D, V.data_ptr(), V.shape[1], vsp, vtp,
+                                                int(self.v_relu), cptr, K, out.data_ptr(), self.D, _stream()),
+                       "fused_layer_pool")
+            return out
+        scores, _, _ = run_layer(score_in, self.w2)
+        _lib.check(lib.pdr_attention_pool(scores.data_ptr(), scores.shape[1], V.data_ptr(), V.shape[1], vsp, vtp,
+                                          int(self.v_relu), cptr, B, npoint, K, self.D, out.data_ptr(), _stream()),
+                   "attention_pool")
         return out
 
 

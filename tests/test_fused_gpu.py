@@ -116,6 +116,21 @@ def test_fused_network_small_config(cuda, split_first, monkeypatch):
     assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
 
 
+def test_optional_fusions_match(cuda, monkeypatch):
+    """The experimental paths (virtual first conv, score+pool epilogue) stay numerically equivalent."""
+    net, fused = _pair(small_fused_config(), 22, cuda)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 256, 3, generator=g).to(cuda)
+    cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
+    ts, label = torch.tensor([9.0, 4.0], device=cuda), torch.tensor([1, 7], device=cuda)
+    base, _ = _cached_eps(net, fused, x, cond, ts, label)
+    for flag in ("FUSE_SCORE_POOL", "USE_VIRTUAL_FIRST"):
+        monkeypatch.setattr(FN, flag, True)
+        got, _ = _cached_eps(net, fused, x, cond, ts, label)
+        monkeypatch.setattr(FN, flag, False)
+        assert ((got - base).abs() / (base.abs() + 1.0)).max() < 1e-3, flag
+
+
 def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
     torch.manual_seed(0)
     net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)            # default (random) init
