@@ -252,8 +252,10 @@ extern "C" int pdr_gather_rows(const float* src, const int* idx, int B, int n, i
 //
 // One workgroup = 128 positions; each wave owns 32 CONSECUTIVE positions whose neighbour indices /
 // empty flags / per-position scalars are fetched with one coalesced load and then broadcast from
-// registers (v_readlane), four positions at a time, so 8 row loads are in flight per wave before the
-// first add.  Lanes stride the columns in float4: every U / V / Y access is a contiguous row segment.
+// registers.  A row is covered by LPR lanes x float4 (LPR = 16 / 32 / 64 by output width), so a wave
+// instruction moves 64 / LPR rows and narrow outputs keep every lane busy; two row groups are in
+// flight per iteration.  Every U / V / Y access is a contiguous row segment.
+template <int LPR>
 __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ U, int ldu, int n_src, const float* __restrict__ V,
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
@@ -261,14 +263,17 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ r2, int rows_per_batch, int K, int Cout, float* __restrict__ Y, int ldy,
     float* __restrict__ partial, int relu_col0) {
   constexpr int TM = 128;
-  __shared__ float red[4][256][2];
+  constexpr int RPI = 64 / LPR;            // rows per wave instruction
+  constexpr int CW = 4 * LPR;              // columns covered per pass
+  __shared__ float red[4][CW][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, cl = lane % LPR;
   const int tpb = (rows_per_batch + TM - 1) / TM;
-  const int b = blockIdx.x / tpb, tb = blockIdx.x - b * tpb;
+  const int bid = pdr::xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = bid / tpb, tb = bid - b * tpb;
   const long row0 = static_cast<long>(b) * rows_per_batch + static_cast<long>(tb) * TM;
   const int nvalid = min(TM, rows_per_batch - tb * TM);
   const float* Ub = U + static_cast<long>(b) * n_src * ldu;
-  // this wave's 32 positions: wrow0 .. wrow0 + 31 (clamped to the tile for the loads, masked later)
   const int wr0 = wave * 32;
   const int myr = min(wr0 + (lane & 31), nvalid - 1);
   const long myp = row0 + myr;
@@ -278,32 +283,33 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
   const float my_s2 = s2 ? s2[myp] : 0.0f;
   const int nrows = max(0, min(32, nvalid - wr0));   // uniform
 
-  for (int c0 = 0; c0 < Cout; c0 += 256) {
-    const int c = c0 + 4 * lane;
+  for (int c0 = 0; c0 < Cout; c0 += CW) {
+    const int c = c0 + 4 * cl;
     const bool cok = c < Cout;   // row widths are padded to a multiple of 4 in ldu / ldv / ldy
     const int cc = cok ? c : 0;
     float4 q1 = make_float4(0, 0, 0, 0), q2 = make_float4(0, 0, 0, 0);
     if (cok && r1) q1 = *reinterpret_cast<const float4*>(r1 + c);
     if (cok && r2) q2 = *reinterpret_cast<const float4*>(r2 + c);
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (int r = 0; r < nrows; r += 4) {
-      float4 u[4], v[4];
-      float t1[4], t2[4];
-      int em[4];
+    for (int r = 0; r < nrows; r += 2 * RPI) {
+      float4 u[2], v[2];
+      float t1[2], t2[2];
+      int em[2], rr[2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int rr = min(r + k, nrows - 1);                      // uniform
-        const int a = __builtin_amdgcn_readlane(my_idx, rr);
-        em[k] = __builtin_amdgcn_readlane(my_empty, rr);
-        t1[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_s1), rr));
-        t2[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_s2), rr));
-        const long q = (row0 + wr0 + rr) / K;
+      for (int k = 0; k < 2; ++k) {
+        rr[k] = r + k * RPI + sub;                               // this lane's row (per sub-group)
+        const int rc = min(rr[k], nrows - 1);
+        const int a = __shfl(my_idx, rc, 64);
+        em[k] = __shfl(my_empty, rc, 64);
+        t1[k] = __shfl(my_s1, rc, 64);
+        t2[k] = __shfl(my_s2, rc, 64);
+        const long q = (row0 + wr0 + rc) / K;
         u[k] = *reinterpret_cast<const float4*>(Ub + static_cast<long>(a) * ldu + cc);
         v[k] = *reinterpret_cast<const float4*>((em[k] ? V0 : V) + q * ldv + cc);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (r + k < nrows && cok) {                                 // r + k < nrows is uniform
+      for (int k = 0; k < 2; ++k) {
+        if (rr[k] < nrows && cok) {
           float4 y;
           if (em[k]) {
             y = v[k];
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
             y.x = __builtin_fmaf(t2[k], q2.x, y.x); y.y = __builtin_fmaf(t2[k], q2.y, y.y);
             y.z = __builtin_fmaf(t2[k], q2.z, y.z); y.w = __builtin_fmaf(t2[k], q2.w, y.w);
           }
-          if (Y) *reinterpret_cast<float4*>(Y + (row0 + wr0 + r + k) * ldy + c) = y;
+          if (Y) *reinterpret_cast<float4*>(Y + (row0 + wr0 + rr[k]) * ldy + c) = y;
           const float e[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -326,19 +332,30 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
       }
     }
     if (partial) {
+      // fold the RPI row sub-groups (lanes with equal `cl`), then the 4 waves through LDS
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        red[wave][4 * lane + j][0] = a1[j];
-        red[wave][4 * lane + j][1] = a2[j];
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+          a1[j] += __shfl_xor(a1[j], off, 64);
+          a2[j] += __shfl_xor(a2[j], off, 64);
+        }
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[wave][4 * cl + j][0] = a1[j];
+          red[wave][4 * cl + j][1] = a2[j];
+        }
       }
       __syncthreads();
       const int cc2 = c0 + threadIdx.x;
-      if (cc2 < Cout) {
+      if (threadIdx.x < CW && cc2 < Cout) {
         const float t1 = (red[0][threadIdx.x][0] + red[1][threadIdx.x][0]) +
                          (red[2][threadIdx.x][0] + red[3][threadIdx.x][0]);
         const float t2 = (red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) +
                          (red[2][threadIdx.x][1] + red[3][threadIdx.x][1]);
-        float* o = partial + (static_cast<long>(blockIdx.x) * Cout + cc2) * 2;
+        float* o = partial + (static_cast<long>(bid) * Cout + cc2) * 2;
         o[0] = t1;
         o[1] = t2;
       }
@@ -363,8 +380,14 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
   const int c4 = (Cout + 3) & ~3;
   if (ldu % 4 || ldv % 4 || ldu < c4 || ldv < c4 || (Y && (ldy % 4 || ldy < c4))) return PDR_EINVAL;
   const int tpb = (rows_per_batch + 127) / 128;
-  hipLaunchKernelGGL(gather_add_kernel, dim3(static_cast<unsigned>(B) * tpb), dim3(256), 0,
-                     pdr::as_stream(stream), U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2,
-                     rows_per_batch, K, Cout, Y, ldy, partial, relu_col0);
+  const dim3 grid(static_cast<unsigned>(B) * tpb);
+  hipStream_t st = pdr::as_stream(stream);
+#define PDR_GA(LPR)                                                                                   \
+  hipLaunchKernelGGL(gather_add_kernel<LPR>, grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
+                     counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0)
+  if (Cout <= 64) PDR_GA(16);
+  else if (Cout <= 128) PDR_GA(32);
+  else PDR_GA(64);
+#undef PDR_GA
   return pdr::check_launch();
 }

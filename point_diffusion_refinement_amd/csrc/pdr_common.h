@@ -75,4 +75,14 @@ __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) {
   return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2.
+// This maps the hardware id to a logical id such that every XCD walks one CONTIGUOUS range of
+// logical ids (so tiles that re-read the same per-cloud source rows share an L2).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nb) {
+  constexpr int X = 8;
+  const int x = bid % X, w = bid / X;
+  const int q = nb / X, r = nb % X;
+  return x * q + (x < r ? x : r) + w;
+}
+
 }  // namespace pdr
