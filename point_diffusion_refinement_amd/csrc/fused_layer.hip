@@ -31,6 +31,8 @@
 // (machine balance ~25 flop/B at the 157 TF fp32-MFMA peak).
 #include "pdr_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -773,6 +775,14 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     for (int sg = 0; sg < in->n_seg; ++sg)
       if (in->seg[sg].gV && in->gcnt && !in->seg[sg].gV0) return PDR_EINVAL;
   }
+  // steady-state layers (float4-staged, no gathered source): wave-specialised kernel
+  static const bool use_ws = []() {
+    const char* e = getenv("PDR_FUSED_WS");   // tuning knob: PDR_FUSED_WS=0 selects the uniform-wave kernel
+    return !(e && e[0] == '0');
+  }();
+  if (use_ws && vec && !gath &&
+      pdr::launch_fused_layer_ws(t.id, radd, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt, ncol, s))
+    return pdr::check_launch();
 #define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC, GATH)                                            \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC, GATH>), grid, dim3(256), 0, s, \
                      *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt)

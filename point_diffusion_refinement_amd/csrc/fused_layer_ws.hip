@@ -1,0 +1,464 @@
+// fused_layer_ws.hip -- wave-specialised form of the fused layer kernel (fused_layer.hip) for the
+// float4-staged, non-gathered case, i.e. every steady-state layer of the reverse step.
+//
+// Why: in fused_layer_kernel every wave both stages the next K-chunk (address arithmetic, prologue
+// math, LDS stores: ~450 issue slots per chunk) and runs the MFMAs of the current one, at 247 VGPRs
+// = 2 waves per SIMD.  PMC on the 512x512 layers: MFMA pipe busy 64 %, waves parked 17 % and
+// issue-stalled 59 % of their cycles.  Here the two jobs belong to different waves of a 512-thread
+// workgroup:
+//   waves 0-3  CONSUMERS  own the accumulators; per chunk: barrier, ds_read + v_mfma only.
+//   waves 4-7  PRODUCERS  global -> registers -> prologue -> LDS for chunk g+1 while chunk g is being
+//                         multiplied; the loads of chunk g+2 are issued before the barrier and fly
+//                         through the next chunk period; they never touch an accumulator.
+// LDS holds two stages; ONE barrier per chunk hands stage g to the consumers and stage g+1 back to
+// the producers.  Workgroups are persistent over row tiles and the chunk sequence runs across tile
+// boundaries, so the first chunk of the next tile is staged during the epilogue of the current one.
+// Register budget 128 (consumers: 64 accumulators, producers: one chunk in flight) = 4 waves / SIMD.
+//
+// Results are bit-identical to fused_layer_kernel: same k order per accumulator, same epilogue.
+#include "pdr_common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // W quads: moved as values (float4 struct copies stay memcpy)
+
+#ifdef PDR_LAB_TRACE
+// development probe (tools/lab): per-chunk timestamps of one consumer and one producer wave of one workgroup
+__device__ unsigned long long pdr_lab_trace[2][4096];
+#define PDR_T(role, slot)                                                                   \
+  do {                                                                                      \
+    if (trace_on && (threadIdx.x & 63) == 0 && (slot) < 4096)                               \
+      pdr_lab_trace[role][slot] = __builtin_amdgcn_s_memtime();                             \
+  } while (0)
+#else
+#define PDR_T(role, slot) do {} while (0)
+#endif
+
+// identity prologue parameters for layers without scale / shift / add: read like the real per-channel
+// arrays (same addressing), so the loads need no branch and no per-lane select
+constexpr int kMaxCin = 4096;
+// (not `const`: a constant-address-space object mixed with global pointers would turn the loads
+// into FLAT loads, which also disable counted vmcnt waits)
+__device__ float k_ones[kMaxCin + 8] = {[0 ... kMaxCin + 7] = 1.0f};
+__device__ float k_zeros[kMaxCin + 8] = {[0 ... kMaxCin + 7] = 0.0f};
+
+// IEEE max without the canonicalising pre-pass fmaxf() compiles to (identical for non-NaN inputs)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int RT, int CT, int WR, int WC, int KC, bool RADD>
+__global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
+    pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
+    const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
+    float* __restrict__ partial, int relu_col0, int n_row_tiles) {
+  static_assert(WR * WC == 4, "4 consumer waves");
+  constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
+  constexpr int C4 = KC / 4;          // float4 columns of an A chunk
+  constexpr int PT = 256;             // producer threads: all four producer waves stage every chunk
+  constexpr int VSTEP = PT / C4;      // rows covered per step
+  constexpr int APT4 = TM / VSTEP;    // float4 of A per producer thread
+  constexpr int TN4 = TN / 4;
+  constexpr int WPT4 = (KC * TN4 + PT - 1) / PT;
+  static_assert(TM % VSTEP == 0, "tile rows");
+  __shared__ float As[2][KC][TM + 1];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC][TN];
+  __shared__ float red[WR][TN][2];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rpb = in.rows_per_batch;
+  const int tpb = (rpb + TM - 1) / TM;
+  const int n0 = blockIdx.y * TN;
+  // chunks per tile, tiles of this workgroup
+  int nch = 0;
+  for (int s = 0; s < in.n_seg; ++s) nch += (in.seg[s].C + KC - 1) / KC;
+  const int my_tiles = (n_row_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) /
+                       static_cast<int>(gridDim.x);
+  const int G = my_tiles * nch;
+  const bool has_partial = partial != nullptr;
+#ifdef PDR_LAB_TRACE
+  const bool trace_on = blockIdx.x == 37 % gridDim.x && blockIdx.y == 0 && (wave == 0 || wave == 4 || wave == 6);
+#endif
+
+  // cursor over (tile, segment, channel offset)
+  struct Cur { int tile, sg, ks, cbase; };
+  // branch-free (scalar selects): a branch between a fetch and the following commit makes the
+  // compiler's wait-count pass fall back to vmcnt(0), which would drain the prefetch
+  auto advance = [&](Cur& c, bool really = true) {
+    const int segC = in.seg[c.sg].C;
+    const int ks1 = c.ks + KC;
+    const bool seg_end = ks1 >= segC;
+    const bool tile_end = seg_end && (c.sg + 1 >= in.n_seg);
+    Cur n;
+    n.ks = seg_end ? 0 : ks1;
+    n.cbase = tile_end ? 0 : (seg_end ? c.cbase + segC : c.cbase);
+    n.sg = tile_end ? 0 : (seg_end ? c.sg + 1 : c.sg);
+    n.tile = tile_end ? c.tile + static_cast<int>(gridDim.x) : c.tile;
+    c.ks = really ? n.ks : c.ks;
+    c.cbase = really ? n.cbase : c.cbase;
+    c.sg = really ? n.sg : c.sg;
+    c.tile = really ? n.tile : c.tile;
+  };
+  auto last_of_tile = [&](const Cur& c) { return c.sg == in.n_seg - 1 && c.ks + KC >= in.seg[c.sg].C; };
+
+  if (wave >= 4) {
+    // =================================== PRODUCERS ===================================
+    // Short bursts of VALU / LDS work between long waits: issue them ahead of the consumers' MFMAs
+    // (an MFMA occupies the matrix pipe for 64 cycles; a delayed staging instruction delays a barrier).
+#ifndef PDR_LAB_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const float lo_pre = in.pre_relu ? 0.0f : -__builtin_inff();
+    const float lo_post = in.post_relu ? 0.0f : -__builtin_inff();
+    const int pt = tid - 256;
+    const int vc4 = pt % C4, vr0 = pt / C4;
+    const int ss_ld = in.ss_ld > 0 ? in.ss_ld : Cin;
+    const bool has_pre = in.pre_relu != 0, has_add = in.add != nullptr;
+    // per-thread byte offsets that do not change from chunk to chunk (full tiles, full chunks): the
+    // per-chunk part of every address is a scalar base, so a fetch costs (almost) no VALU work
+    unsigned a_off[APT4], r_off[RADD ? APT4 : 1], w_off[WPT4];
+    int off_sg = -1;                                   // segment a_off was built for
+    {
+      const int nmax = ldw - n0 - 4;                   // last in-row float4 offset
+#pragma unroll
+      for (int i = 0; i < WPT4; ++i) {
+        const int e = pt + PT * i;
+        const int k = e / TN4, n4 = e - k * TN4;
+        w_off[i] = static_cast<unsigned>(min(k, KC - 1) * ldw + min(4 * n4, nmax)) * 4u;
+      }
+      if constexpr (RADD) {
+#pragma unroll
+        for (int i = 0; i < APT4; ++i)
+          r_off[i] = static_cast<unsigned>((vr0 + VSTEP * i) * in.rseg.ld + 4 * vc4) * 4u;
+      }
+    }
+    // one chunk in registers (plain arrays: as members of a struct one W quad ended up in scratch)
+    float4 Rrv[APT4], Rrrv[RADD ? APT4 : 1];
+    f32x4 Rrw[WPT4];
+    float Rps[4], Rph[4], Rpa[4];
+    int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
+    // fetch: chunk at cursor c -> registers (address arithmetic + loads only)
+    auto fetch = [&](const Cur& c) {
+      const int b = c.tile / tpb, tb = c.tile - b * tpb;
+      const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
+      const int nvalid = min(TM, rpb - tb * TM);
+      const pdr_seg_t seg = in.seg[c.sg];
+      const int shift = __builtin_ctz(seg.row_div);
+      Rkmax = min(KC, seg.C - c.ks);
+      // prologue parameters of channels cbase + ks + 4 vc4 + j
+      const float* sc_b = (in.scale ? in.scale + static_cast<long>(b) * ss_ld : k_ones) + c.cbase + c.ks;
+      const float* sh_b = (in.shift ? in.shift + static_cast<long>(b) * ss_ld : k_zeros) + c.cbase + c.ks;
+      const float* ad_b = (in.add ? in.add + static_cast<long>(b) * in.add_ld : k_zeros) + c.cbase + c.ks;
+      // every load = uniform base (scalar registers) + 32-bit per-thread byte offset
+      const char* ab = reinterpret_cast<const char*>(seg.ptr + (row0 >> shift) * seg.ld + c.ks);
+      const char* wb = reinterpret_cast<const char*>(Wt + static_cast<long>(c.cbase + c.ks) * ldw + n0);
+      unsigned ao[APT4], ro[RADD ? APT4 : 1], wo[WPT4], po[4];
+      if (Rkmax == KC && nvalid == TM) {
+        // ---- fast path (uniform): the precomputed per-thread offsets
+        if (off_sg != c.sg) {
+          off_sg = c.sg;
+#pragma unroll
+          for (int i = 0; i < APT4; ++i)
+            a_off[i] = static_cast<unsigned>(((vr0 + VSTEP * i) >> shift) * seg.ld + 4 * vc4) * 4u;
+        }
+        Rcvalid = 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) po[j] = 16u * vc4 + 4u * j;
+#pragma unroll
+        for (int i = 0; i < APT4; ++i) ao[i] = a_off[i];
+        if constexpr (RADD) {
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) ro[i] = r_off[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WPT4; ++i) wo[i] = w_off[i];
+      } else {
+        // ---- general path: partial chunk (last of a segment) or partial row tile
+        const int cl = 4 * vc4;                                   // relative to ks
+        const int clc = min(cl, ((seg.C + 3) & ~3) - 4 - c.ks);   // keep the 16-B load inside the row
+        Rcvalid = cl == clc ? min(4, seg.C - c.ks - clc) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) po[j] = static_cast<unsigned>(min(clc + j, seg.C - 1 - c.ks)) * 4u;
+#pragma unroll
+        for (int i = 0; i < APT4; ++i) {
+          // rows beyond nvalid re-read the tile's last row; masked in the epilogue
+          const int r = min(vr0 + VSTEP * i, nvalid - 1);
+          ao[i] = static_cast<unsigned>((r >> shift) * seg.ld + clc) * 4u;
+          if constexpr (RADD) ro[i] = static_cast<unsigned>(r * in.rseg.ld + clc) * 4u;
+        }
+        const int nmax = ldw - n0 - 4;   // last in-row float4 offset
+#pragma unroll
+        for (int i = 0; i < WPT4; ++i) {
+          const int e = pt + PT * i;
+          const int k = e / TN4, n4 = e - k * TN4;
+          wo[i] = static_cast<unsigned>(min(k, Rkmax - 1) * ldw + min(4 * n4, nmax)) * 4u;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        Rps[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sc_b) + po[j]);
+        Rph[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sh_b) + po[j]);
+        Rpa[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ad_b) + po[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < APT4; ++i) Rrv[i] = *reinterpret_cast<const float4*>(ab + ao[i]);
+      if constexpr (RADD) {
+        const char* rb = reinterpret_cast<const char*>(in.rseg.ptr + row0 * in.rseg.ld + c.cbase + c.ks);
+#pragma unroll
+        for (int i = 0; i < APT4; ++i) Rrrv[i] = *reinterpret_cast<const float4*>(rb + ro[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < WPT4; ++i) Rrw[i] = *reinterpret_cast<const f32x4*>(wb + wo[i]);
+    };
+    // commit: prologue math + LDS stores into stage st.  The staging instructions compete with the
+    // consumers' MFMAs for issue slots (measured ~20 cycles per instruction next to two MFMA-bound
+    // waves), so the instruction count is what matters here:
+    //  - v_max_f32 directly (fmaxf adds a canonicalising v_max per operand);
+    //  - channel masks only in a segment's last, partial chunk (uniform branch);
+    //  - W is stored unmasked: rows k >= kmax meet zeroed A columns (and hold finite, clamped-row
+    //    data), columns >= Cout are never stored or counted.
+    auto commit = [&](int st) {
+      auto stage_a = [&](auto masked, auto pre, auto add) {
+        constexpr bool MASKED = decltype(masked)::value, PRE = decltype(pre)::value, ADD = decltype(add)::value;
+#pragma unroll
+        for (int i = 0; i < APT4; ++i) {
+          const float x[4] = {Rrv[i].x, Rrv[i].y, Rrv[i].z, Rrv[i].w};
+          float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if constexpr (RADD) {
+            q[0] = Rrrv[i].x; q[1] = Rrrv[i].y; q[2] = Rrrv[i].z; q[3] = Rrrv[i].w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = x[j];
+            if constexpr (PRE) v = vmax(v, lo_pre);
+            v = __builtin_fmaf(v, Rps[j], Rph[j]);
+            v = vmax(v, lo_post);
+            if constexpr (ADD) v = v + Rpa[j];
+            if constexpr (RADD) v = v + q[j];
+            if constexpr (MASKED) v = j < Rcvalid ? v : 0.0f;
+            As[st][4 * vc4 + j][vr0 + VSTEP * i] = v;
+          }
+        }
+      };
+      using T = std::true_type;
+      using F = std::false_type;
+      if (Rkmax < KC) stage_a(T(), T(), T());          // partial chunk: general form
+      else if (has_pre) stage_a(F(), T(), T());
+      else if (has_add) stage_a(F(), F(), T());
+      else stage_a(F(), F(), F());
+#pragma unroll
+      for (int i = 0; i < WPT4; ++i) {
+        const int e = pt + PT * i;
+        const int k = e / TN4, n4 = e - k * TN4;
+        if (KC * TN4 % PT == 0 || e < KC * TN4) *reinterpret_cast<f32x4*>(&Bs[st][k][4 * n4]) = Rrw[i];
+      }
+    };
+
+    // Per chunk: wait for its loads (issued one chunk period earlier), stage it, issue the loads of
+    // the next chunk, barrier.  The staging math is spread over all four producer waves because its
+    // LATENCY (not its issue cost) is what can delay the barrier: next to two MFMA-bound waves a
+    // VALU instruction waits ~a whole MFMA issue slot.
+    Cur co{static_cast<int>(blockIdx.x), 0, 0, 0};
+    bool prev_last = false;
+    fetch(co);
+    for (int g = 0; g < G; ++g) {
+      PDR_T(1, 4 * g + 0);
+#ifdef PDR_LAB_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PDR_T(1, 4 * g + 3);
+#endif
+      commit(g & 1);
+      PDR_T(1, 4 * g + 1);
+      const bool last = last_of_tile(co);
+      advance(co, g + 1 < G);
+      fetch(co);                                    // past the end: re-reads the last chunk
+      PDR_T(1, 4 * g + 2);
+      if (prev_last && has_partial) __syncthreads();   // E: pairs with the consumers' stats barrier
+      __syncthreads();                                 // B(g): stage g full, stage g+1 free
+      prev_last = last;
+    }
+    if (has_partial) __syncthreads();                  // E of the last tile
+    return;
+  }
+
+  // =================================== CONSUMERS ===================================
+  const int lane = tid & 63;
+  const int wr = wave % WR, wc = wave / WR;
+  const int il = lane & 31, hi = lane >> 5;
+  float bias_r[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = n0 + (wc * CT + j) * 32 + il;
+    bias_r[j] = (bias && col < Cout) ? bias[col] : 0.0f;
+  }
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  Cur cur{static_cast<int>(blockIdx.x), 0, 0, 0};
+  for (int g = 0; g < G; ++g) {
+    PDR_T(0, 4 * g + 0);
+    __syncthreads();   // B(g)
+    PDR_T(0, 4 * g + 1);
+    const int st = g & 1;
+    const int ksteps = (min(KC, in.seg[cur.sg].C - cur.ks) + 1) >> 1;
+    for (int kk = 0; kk < ksteps; ++kk) {
+      float a[RT], w[CT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) a[i] = As[st][2 * kk + hi][(wr * RT + i) * 32 + il];
+#pragma unroll
+      for (int j = 0; j < CT; ++j) w[j] = Bs[st][2 * kk + hi][(wc * CT + j) * 32 + il];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], w[j], acc[i][j], 0, 0, 0);
+    }
+    PDR_T(0, 4 * g + 2);
+    if (last_of_tile(cur)) {
+      // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)
+      const int tile = cur.tile;
+      const int b = tile / tpb, tb = tile - b * tpb;
+      const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
+      const int nvalid = min(TM, rpb - tb * TM);
+      const bool rows_full = nvalid == TM;   // uniform
+      // opaque copy: keeps the per-row store offsets from being hoisted out of the chunk loop
+      // (64 live 64-bit addresses would spill)
+      int il_e = il, hi_e = hi;
+      asm volatile("" : "+v"(il_e), "+v"(hi_e));
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int cl = (wc * CT + j) * 32 + il_e;
+        const int col = n0 + cl;
+        const bool colok = col < Cout;
+        const float bv = bias_r[j];
+        const bool relu_stat = col >= relu_col0;
+        float s1 = 0.0f, s2 = 0.0f;
+        float* ybase = Y + row0 * ldy + col;
+        if (colok && in.oadd) {
+          const int osh = __builtin_ctz(in.oadd_div);
+          const float* ob = in.oadd + col;
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rl = min((wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e, nvalid - 1);
+              acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
+            }
+          }
+        }
+        if (colok) {
+          if (rows_full) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
+                const float y = acc[i][j][r] + bv;
+#ifndef PDR_LAB_NO_STORE
+                ybase[rl * ldy] = y;
+#else
+                if (y == 123.456f) ybase[rl * ldy] = y;
+#endif
+                const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+                s1 += f;
+                s2 = __builtin_fmaf(f, f, s2);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
+                const float y = acc[i][j][r] + bv;
+                if (rl < nvalid) {
+                  ybase[rl * ldy] = y;
+                  const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+                  s1 += f;
+                  s2 = __builtin_fmaf(f, f, s2);
+                }
+              }
+            }
+          }
+        }
+        if (has_partial) {
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (hi_e == 0) {
+            red[wr][cl][0] = s1;
+            red[wr][cl][1] = s2;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      }
+      if (has_partial) {
+        __syncthreads();   // E
+        if (tid < TN && n0 + tid < Cout) {
+          float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+          for (int w = 0; w < WR; ++w) {
+            s1 += red[w][tid][0];
+            s2 += red[w][tid][1];
+          }
+          float* o = partial + (static_cast<long>(tile) * Cout + n0 + tid) * 2;
+          o[0] = s1;
+          o[1] = s2;
+        }
+      }
+    }
+    PDR_T(0, 4 * g + 3);
+    advance(cur);
+  }
+}
+
+}  // namespace
+
+#ifdef PDR_LAB_TRACE
+extern "C" int pdr_lab_trace_read(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pdr_lab_trace), sizeof(unsigned long long) * 2 * 4096) == hipSuccess ? 0 : -1;
+}
+#endif
+
+namespace pdr {
+
+// Launches the wave-specialised kernel for tile variant `id` (pick_tile() of fused_layer.hip).
+// Returns false when the variant has no wave-specialised instantiation.
+bool launch_fused_layer_ws(int id, bool radd, const pdr_layer_in_t& in, int Cin, const float* Wt, int ldw,
+                           const float* bias, int Cout, float* Y, int ldy, float* partial, int relu_col0,
+                           int n_row_tiles, int ncol, hipStream_t s) {
+  // persistent: at most 2 workgroups per CU, all co-resident
+  long gx = n_row_tiles;
+  const long cap = (512 + ncol - 1) / ncol;
+  if (gx > cap) gx = cap;
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
+#define PDR_WS(RT, CT, WR, WC, KC)                                                                      \
+  do {                                                                                                  \
+    if (radd)                                                                                           \
+      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, true>), grid, dim3(512), 0, s, in,  \
+                         Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);            \
+    else                                                                                                \
+      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false>), grid, dim3(512), 0, s, in, \
+                         Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);            \
+  } while (0)
+  switch (id) {
+    case 4: PDR_WS(2, 2, 2, 2, 32); return true;
+    default: return false;
+  }
+#undef PDR_WS
+}
+
+}  // namespace pdr

@@ -1,0 +1,80 @@
+"""Micro-benchmark of pdr_fused_layer at the layer shapes of the DDPM config (B=32).
+
+    python -m tools.fused_layer_bench [--lib path/to/libpdr_lab.so]
+
+--lib times an experimental build of the kernels (development only; the product always loads the in-tree
+libpdr_hip.so).  Prints us / TFLOP/s / algorithmic GB/s per shape.
+"""
+import argparse
+import ctypes
+
+import torch
+
+from point_diffusion_refinement_amd import _lib
+
+SHAPES = [  # (rows per batch element, Cin, Cout) at B = 32
+    (16384, 128, 128), (16384, 171, 128), (8192, 128, 128), (8192, 331, 128), (2048, 256, 256), (2048, 331, 256),
+    (512, 512, 512), (512, 651, 256), (65536, 32, 32), (32768, 64, 64), (65536, 41, 32), (8192, 64, 128),
+    (4096, 512, 512), (16384, 512, 512), (16384, 256, 256),   # steady-state probes (not network shapes)
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--zeros", action="store_true", help="zero operands (DVFS probe: data-dependent power)")
+    ap.add_argument("--only", type=int, default=None, help="index into SHAPES")
+    args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = args.lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B = args.batch
+    st = torch.cuda.current_stream().cuda_stream
+    tot = 0.0
+    for rpb, Cin, Cout in (SHAPES if args.only is None else [SHAPES[args.only]]):
+        P = B * rpb
+        ldx = (Cin + 3) // 4 * 4
+        X = torch.randn(P, ldx, device=dev)
+        ldw = (Cout + 3) // 4 * 4
+        Wt = torch.randn(Cin, ldw, device=dev) * 0.05
+        bias = torch.randn(Cout, device=dev)
+        scale = torch.rand(B, Cin, device=dev) + 0.5
+        shift = torch.randn(B, Cin, device=dev)
+        if args.zeros:
+            X.zero_(), Wt.zero_(), bias.zero_(), shift.zero_()
+        Y = torch.empty(P, ldw, device=dev)
+        tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+        tpb = (rpb + tm - 1) // tm
+        partial = torch.empty(B * tpb, Cout, 2, device=dev)
+        li = _lib.LayerIn()
+        li.n_seg = 1
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, ldx, 1
+        li.scale, li.shift = scale.data_ptr(), shift.data_ptr()
+        li.pre_relu, li.post_relu, li.rows_per_batch = 0, 1, rpb
+
+        def call():
+            _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout,
+                                           Y.data_ptr(), ldw, partial.data_ptr(), Cout, st), "fused_layer")
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / args.reps * 1e3
+        tot += us
+        tf = 2.0 * P * Cin * Cout / us / 1e6
+        gb = 4.0 * P * (Cin + Cout) / us / 1e3
+        print("rpb=%6d Cin=%4d Cout=%4d variant=%d: %8.1f us %6.1f TF %6.0f GB/s" %
+              (rpb, Cin, Cout, lib.pdr_fused_layer_variant(rpb, Cout), us, tf, gb))
+    print("total %.1f us" % tot)
+
+
+if __name__ == "__main__":
+    main()
