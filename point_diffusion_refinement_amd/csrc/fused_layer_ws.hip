@@ -455,7 +455,12 @@ bool launch_fused_layer_ws(int id, bool radd, const pdr_layer_in_t& in, int Cin,
                          Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);            \
   } while (0)
   switch (id) {
+    case 0: PDR_WS(2, 1, 4, 1, 16); return true;
+    case 1: PDR_WS(2, 2, 4, 1, 16); return true;
+    case 2: PDR_WS(1, 3, 4, 1, 32); return true;
+    case 3: PDR_WS(1, 5, 4, 1, 32); return true;
     case 4: PDR_WS(2, 2, 2, 2, 32); return true;
+    case 5: PDR_WS(1, 2, 2, 2, 32); return true;
     default: return false;
   }
 #undef PDR_WS

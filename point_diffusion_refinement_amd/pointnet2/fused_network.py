@@ -138,6 +138,23 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+_XYZ4 = {}
+
+
+def xyz4(t):
+    """(B, n, C) channel-last rows padded to a multiple of 4 floats (cached per forward): as a C-wide segment
+    with a 16-byte-aligned leading dimension they qualify for the float4-staged kernels; ld = 3 (coordinates)
+    or 35 would force the scalar-load path.  Returns the padded tensor (last dim = ld)."""
+    if t.shape[-1] % 4 == 0:
+        return t
+    key = (t.data_ptr(), tuple(t.shape))
+    hit = _XYZ4.get(key)
+    if hit is None:
+        hit = torch.nn.functional.pad(t, (0, -t.shape[-1] % 4)).contiguous()
+        _XYZ4[key] = hit
+    return hit
+
+
 def plain(t2d, B, rows_per_batch, row_div=1, C=None):
     """Act over a (rows, ld) tensor whose first C columns are the channels (ld may be padded)."""
     rows, ld = t2d.shape
@@ -464,9 +481,9 @@ class SplitFirstConv:
         lib = _lib.load()
         B, n, Cs = src_feats_cl.shape
         m = query_xyz.shape[1]
-        u_in = Act([(src_feats_cl, 0, Cs, Cs, 1), (src_xyz, 0, 3, 3, 1)], B * n, B, n)
+        u_in = Act([(xyz4(src_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
         U, _, _ = run_layer(u_in, self.U)
-        q_in = plain(query_xyz.reshape(B * m, 3), B, m)
+        q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
         V, _, _ = run_layer(q_in, self.V)
         V0 = None
         if counts is not None:
@@ -581,7 +598,7 @@ class FusedKnnFP:
                           K)
         Cs = unknown_feats_cl.shape[2]
         x2 = Act([(interp, 0, self.att.D, interp.shape[1], 1),
-                  (unknown_feats_cl, 0, Cs, Cs, 1), (unknown, 0, 3, 3, 1)], B * n, B, n)
+                  (xyz4(unknown_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(unknown), 0, 3, 4, 1)], B * n, B, n)
         h2, _, _, _ = self.mlp2(x2, bank, relu_stats_extra=False)
         return materialize(h2).view(B, n, -1)
 
@@ -649,6 +666,7 @@ class FusedCloudConditionNet:
             return net(pointcloud, condition, ts=ts, label=label,
                        use_retained_condition_feature=use_retained_condition_feature)
         B, N, _ = pointcloud.shape
+        _XYZ4.clear()
         xyz = pointcloud[:, :, 0:3].contiguous()
         feat0 = torch.cat([pointcloud[:, :, 3:], xyz / net.scale_factor], dim=2).contiguous() \
             if pointcloud.shape[2] > 3 else (xyz / net.scale_factor)
@@ -716,7 +734,7 @@ class FusedCloudConditionNet:
         mapped = self.dec_map[0](l_uvw[0], dec_cl[0], l_xyz[0], l_feat[0], bank, subset=False,
                                  neigh=fm_neigh[fm_key(0, self.dec_map[0])])
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
-        head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz, 0, 3, 3, 1)], B * N, B, N)
+        head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz4(xyz), 0, 3, 4, 1)], B * N, B, N)
         Y, part, tpb = run_layer(head_in, self.head1, stats=True)
         s, t = self.head_norm.fold([(part, 0, self.head1.Cout, tpb, 1.0)], B, self.head1.Cout, N)
         out, _, _ = run_layer(Act([(Y, 0, self.head1.Cout, Y.shape[1], 1)], B * N, B, N, scale=s, shift=t,

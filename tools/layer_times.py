@@ -37,8 +37,15 @@ def instrument(records):
             src_bytes += 4 * sg[2] * act.P // sg[4]
         if act.radd is not None:
             src_bytes += 4 * act.C * act.P
+        def aligned(sg):
+            t, off, C, ld = sg[:4]
+            return (t.data_ptr() + 4 * off) % 16 == 0 and ld % 4 == 0 and ld >= (C + 3) // 4 * 4
+        vec = all(aligned(sg) for sg in act.segs)
+        if act.radd is not None:
+            vec = vec and len(act.segs) == 1 and aligned(act.radd)
+        desc = "+".join("%d/%d%s" % (sg[2], sg[3], "" if aligned(sg) else "!") for sg in act.segs)
         return dict(P=act.P, Cin=conv.Cin, Cout=conv.Cout, bytes=src_bytes + 4 * conv.Cout * act.P,
-                    flops=2 * act.P * conv.Cin * conv.Cout)
+                    flops=2 * act.P * conv.Cin * conv.Cout, vec=vec, desc=desc + (" radd" if act.radd is not None else ""))
 
     FN.run_layer = wrap("fused_layer", FN.run_layer, layer_meta)
     FN.group_build = wrap("group_build", FN.group_build,
@@ -91,8 +98,11 @@ def main():
         print("%-12s %7.2f ms  (%d launches)" % (k, v, sum(1 for r in rows if r[1] == k)))
     print("%-12s %9s %5s %5s %8s %8s %8s" % ("kernel", "P", "Cin", "Cout", "ms", "GB/s", "TFLOP/s"))
     for ms, name, m in sorted(rows, key=lambda r: -r[0])[:args.top]:
-        print("%-12s %9d %5d %5d %8.3f %8.0f %8.1f" % (name, m["P"], m["Cin"], m["Cout"], ms,
-                                                         m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9))
+        print("%-12s %9d %5d %5d %8.3f %8.0f %8.1f  %s %s" % (name, m["P"], m["Cin"], m["Cout"], ms,
+                                                         m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9,
+                                                         "" if m.get("vec", True) else "SCALAR", m.get("desc", "")))
+    nonvec = [(ms, m) for ms, name, m in rows if name == "fused_layer" and not m.get("vec", True)]
+    print("non-vector fused_layer launches: %d, %.3f ms" % (len(nonvec), sum(r[0] for r in nonvec)))
 
 
 if __name__ == "__main__":
