@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--unfused", action="store_true",
                     help="layer-by-layer PyTorch execution over the native ops instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the live roofline of the dominant kernel")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -156,7 +157,7 @@ def main():
         "first_uncached_step_ms": round(first_step_s * 1e3, 2),
         "gemm_tflops": round(value * GEMM_GFLOP_PER_CLOUD_STEP / 1e3, 2),
     }
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not args.no_roofline:
         try:
             from tools.kernel_roofline import dominant_kernel_roofline
             if args.unfused:
@@ -164,8 +165,8 @@ def main():
             out["roofline"] = dominant_kernel_roofline(sampler)
         except Exception as e:  # never lose the headline number to an instrumentation problem
             out["roofline"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,8 +1,8 @@
 """Live roofline of the dominant hand-written kernel of the reverse step (used by bench.py).
 
-The dominant kernel (largest share of the step in profiles/*_kernel_stats.txt) is
-`fused_layer_kernel<2,2,2,2,32,false>`: the 128 x 128-tile fp32-MFMA layer kernel
-(csrc/fused_layer.hip) that evaluates the wide 1x1-conv GEMMs of the SA / feature-transfer /
+The dominant kernel (largest share of the step in profiles/*_kernel_stats.csv) is
+`fused_layer_ws_kernel<2,2,2,2,32,false>`: the wave-specialised 128 x 128-tile fp32-MFMA layer kernel
+(csrc/fused_layer_ws.hip) that evaluates the wide 1x1-conv GEMMs of the SA / feature-transfer /
 kNN-FP blocks.  Its roof is the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
 
 Every launch of that instantiation inside a reverse step is bracketed with HIP events recorded on
@@ -12,14 +12,33 @@ over `reps` eager repetitions of the step:
            = (average algorithmic flops per launch) / (average launch duration)
 with algorithmic flops of a launch = 2 * P * Cin * Cout (P positions, no padding counted).
 """
+import json
+import os
+
 import torch
 
 from point_diffusion_refinement_amd import _lib
 from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
 
 DOMINANT_VARIANT = 4          # pdr_fused_layer_variant(): 128 x 128 tile, 2-D grid
-DOMINANT_SYMBOL = "fused_layer_kernel<2, 2, 2, 2, 32, false>"
+DOMINANT_SYMBOL = "fused_layer_ws_kernel<2, 2, 2, 2, 32, false>"
 FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                            "r1_pmc_traffic.json")
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh: FETCH_SIZE
+    and WRITE_SIZE in separate rocprofv3 runs of this bench, FETCH_SIZE doubled per the gfx950 correction), or None."""
+    try:
+        for k in json.load(open(TRAFFIC_FILE))["kernels"]:
+            if DOMINANT_SYMBOL in k["kernel"]:
+                return k["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def dominant_kernel_roofline(sampler, reps=3):
@@ -53,7 +72,7 @@ def dominant_kernel_roofline(sampler, reps=3):
     n = len(records)
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": measured_traffic(),
             "kernel": DOMINANT_SYMBOL, "launches_per_step": n // reps,
             "avg_launch_us": round(ms / n * 1e3, 2), "avg_gflop_per_launch": round(flops / n / 1e9, 3),
             "algorithmic_GBps": round(byts / (ms * 1e-3) / 1e9, 1),
