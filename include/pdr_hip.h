@@ -116,6 +116,16 @@ int pdr_three_interpolate_grad(const float *grad_out, const int *idx,
 int pdr_knn_points(const float *x, const float *y, int B, int n1, int n2, int K,
                    float *dists, int64_t *idx, float *nn, pdr_stream_t stream);
 
+/* Backward of pdr_knn_points w.r.t. both clouds (pytorch3d knn_points backward, norm 2;
+ * makes chamfer_loss_new.py:149-167 / calc_cd :234-245 differentiable as train.py:518 needs;
+ * K = 1 cross-check: chamfer3D.cu:155-195):
+ *   grad_x[p] = sum_k 2 g[p,k] (x[p] - y[idx[p,k]]),  grad_y[j] = -sum_{idx[p,k] = j} (same term).
+ * idx < 0 (padding) is skipped.  grad_x (B,n1,3) is overwritten; grad_y (B,n2,3) is zeroed on the
+ * stream and accumulated with float atomics (summation order not fixed). */
+int pdr_knn_points_grad(const float *x, const float *y, const int64_t *idx,
+                        const float *grad_dists, int B, int n1, int n2, int K,
+                        float *grad_x, float *grad_y, pdr_stream_t stream);
+
 /* ---- approximate EMD --------------------------------------------------------
  * approxmatch_forward(xyz1 (B,n,3), xyz2 (B,m,3)) -> match (B,m,n)
  *                                          emd_kernel.cu:29-161, host :174-196

@@ -317,6 +317,41 @@ int pdr_oracle_knn(const float *x, const float *y, int B, int n1, int n2, int K,
   return 0;
 }
 
+/* ---------------------------------------------------------------- kNN backward
+ * pytorch3d.ops.knn_points backward (un-vendored dependency of the reference: call
+ * sites chamfer_loss_new.py:149-150,166-167 make calc_cd differentiable, used as the
+ * refinement loss train.py:518-533).  Published algorithm (norm 2): for every (p, k)
+ * with a valid index j: diff = 2 * grad_dists[p,k] * (x[p] - y[j]); grad_x[p] += diff;
+ * grad_y[j] -= diff.  In-tree cross-check for K = 1: chamfer3D.cu:155-195.
+ * Sequential accumulation order (p ascending, k ascending); the GPU kernel uses
+ * atomics for grad_y, parity tolerance 1e-5 relative.
+ */
+int pdr_oracle_knn_grad(const float *x, const float *y, const int64_t *idx,
+                        const float *grad_dists, int B, int n1, int n2, int K,
+                        float *grad_x, float *grad_y) {
+  memset(grad_x, 0, sizeof(float) * (size_t)B * n1 * 3);
+  memset(grad_y, 0, sizeof(float) * (size_t)B * n2 * 3);
+  for (int b = 0; b < B; ++b) {
+    const float *q = x + (size_t)b * n1 * 3;
+    const float *p = y + (size_t)b * n2 * 3;
+    float *gq = grad_x + (size_t)b * n1 * 3;
+    float *gp = grad_y + (size_t)b * n2 * 3;
+    for (int j = 0; j < n1; ++j) {
+      for (int t = 0; t < K; ++t) {
+        const int64_t k = idx[((size_t)b * n1 + j) * K + t];
+        if (k < 0) continue;
+        const float g = 2.0f * grad_dists[((size_t)b * n1 + j) * K + t];
+        for (int c = 0; c < 3; ++c) {
+          const float d = g * (q[j * 3 + c] - p[k * 3 + c]);
+          gq[j * 3 + c] += d;
+          gp[k * 3 + c] -= d;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
 /* ---------------------------------------------------------------- EMD
  * PytorchEMD/cuda/emd_kernel.cu:29-161 (approxmatch), host :174-196.
  * match (B,m,n) indexed [(l)*n + k]; launch <<<32,512>>>: the per-thread

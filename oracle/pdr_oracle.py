@@ -150,6 +150,20 @@ def knn(x, y, K):
     return d, idx
 
 
+def knn_grad(x, y, idx, grad_dists):
+    """Backward of knn(): (grad_x (B,n1,3), grad_y (B,n2,3))."""
+    x, y, grad_dists = _f32(x), _f32(y), _f32(grad_dists)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    B, n1, _ = x.shape
+    n2 = y.shape[1]
+    K = idx.shape[2]
+    gx = np.zeros((B, n1, 3), dtype=np.float32)
+    gy = np.zeros((B, n2, 3), dtype=np.float32)
+    _chk(lib().pdr_oracle_knn_grad(_p(x), _p(y), _p(idx), _p(grad_dists), B, n1, n2, int(K), _p(gx), _p(gy)),
+         "knn_grad")
+    return gx, gy
+
+
 def approxmatch(xyz1, xyz2):
     xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
     B, n, _ = xyz1.shape

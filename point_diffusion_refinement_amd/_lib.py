@@ -32,6 +32,7 @@ SIGNATURES = {
     "pdr_three_interpolate": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_three_interpolate_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_knn_points": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pdr_knn_points_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "pdr_emd_workspace_bytes": (_Z, [_I, _I, _I]),
     "pdr_matchcost_workspace_bytes": (_Z, [_I, _I, _I]),
     "pdr_approxmatch": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),

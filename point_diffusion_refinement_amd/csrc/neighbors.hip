@@ -129,3 +129,60 @@ extern "C" int pdr_knn_points(const float* x, const float* y, int B, int n1, int
   if (K <= 16) return launch_knn<16>(x, y, B, n1, n2, K, dists, idx, nn, s);
   return launch_knn<32>(x, y, B, n1, n2, K, dists, idx, nn, s);
 }
+
+// ---- kNN backward (pytorch3d knn_points backward, norm 2; cf. chamfer3D.cu:155-195 for K = 1) ----
+// One thread per query point: its K terms are summed in registers (k ascending, as the oracle) and
+// written once; the scattered grad_y contributions use float atomics (pytorch3d does the same), so
+// grad_y is reproducible only up to the summation order.
+namespace {
+__global__ __launch_bounds__(256) void knn_grad_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ y,
+                                                       const int64_t* __restrict__ idx,
+                                                       const float* __restrict__ gd, int n1, int n2, int K,
+                                                       float* __restrict__ gx, float* __restrict__ gy) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n1) return;
+  const float* q = x + (static_cast<size_t>(b) * n1 + j) * 3;
+  const float* p = y + static_cast<size_t>(b) * n2 * 3;
+  float* gp = gy + static_cast<size_t>(b) * n2 * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  for (int t = 0; t < K; ++t) {
+    const int64_t k = idx[(static_cast<size_t>(b) * n1 + j) * K + t];
+    if (k < 0) continue;
+    const float g = 2.0f * gd[(static_cast<size_t>(b) * n1 + j) * K + t];
+    const float dx = g * (qx - p[k * 3 + 0]);
+    const float dy = g * (qy - p[k * 3 + 1]);
+    const float dz = g * (qz - p[k * 3 + 2]);
+    ax += dx;
+    ay += dy;
+    az += dz;
+    atomicAdd(gp + k * 3 + 0, -dx);
+    atomicAdd(gp + k * 3 + 1, -dy);
+    atomicAdd(gp + k * 3 + 2, -dz);
+  }
+  float* o = gx + (static_cast<size_t>(b) * n1 + j) * 3;
+  o[0] = ax;
+  o[1] = ay;
+  o[2] = az;
+}
+}  // namespace
+
+extern "C" int pdr_knn_points_grad(const float* x, const float* y, const int64_t* idx,
+                                   const float* grad_dists, int B, int n1, int n2, int K, float* grad_x,
+                                   float* grad_y, pdr_stream_t stream) {
+  if (B < 0 || n1 < 0 || n2 < 0 || K <= 0) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  hipStream_t s = pdr::as_stream(stream);
+  if (n2 > 0) {
+    if (!grad_y) return PDR_EINVAL;
+    if (hipMemsetAsync(grad_y, 0, sizeof(float) * static_cast<size_t>(B) * n2 * 3, s) != hipSuccess)
+      return PDR_ELAUNCH;
+  }
+  if (n1 == 0) return PDR_OK;
+  if (!x || !idx || !grad_dists || !grad_x || (n2 > 0 && !y)) return PDR_EINVAL;
+  hipLaunchKernelGGL(knn_grad_kernel, dim3((n1 + 255) / 256, B), dim3(256), 0, s, x, y, idx, grad_dists, n1, n2,
+                     K, grad_x, grad_y);
+  return pdr::check_launch();
+}

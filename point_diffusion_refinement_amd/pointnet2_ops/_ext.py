@@ -166,14 +166,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
-def knn_points(p1, p2, K, return_nn=False):
-    """pytorch3d.ops.knn.knn_points on dense equal-length clouds:
-    (B,n1,3), (B,n2,3) -> (dists (B,n1,K) f32 squared ascending, idx (B,n1,K) i64, nn (B,n1,K,3) | None)."""
-    _req(p1, "p1", torch.float32)
-    _req(p2, "p2", torch.float32)
-    _same_device(p1, p2)
-    if p1.shape[2] != 3 or p2.shape[2] != 3:
-        raise RuntimeError("knn_points: only D=3 is built")
+def _knn_forward(p1, p2, K, return_nn):
     B, n1, _ = p1.shape
     n2 = p2.shape[1]
     dists = torch.empty((B, n1, K), dtype=torch.float32, device=p1.device)
@@ -184,3 +177,48 @@ def knn_points(p1, p2, K, return_nn=False):
                                               idx.data_ptr(), nn.data_ptr() if return_nn else None, _stream()),
                    "knn_points")
     return dists, idx, nn
+
+
+class _KnnDists(torch.autograd.Function):
+    """Differentiable squared distances of knn_points (pytorch3d `_knn_points` backward, norm 2)."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, K):
+        dists, idx, _ = _knn_forward(p1, p2, K, False)
+        ctx.save_for_backward(p1, p2, idx)
+        ctx.mark_non_differentiable(idx)
+        return dists, idx
+
+    @staticmethod
+    def backward(ctx, grad_dists, _grad_idx):
+        p1, p2, idx = ctx.saved_tensors
+        B, n1, _ = p1.shape
+        n2, K = p2.shape[1], idx.shape[2]
+        g = grad_dists.contiguous().float()
+        g1 = torch.empty_like(p1)
+        g2 = torch.empty_like(p2)
+        with torch.cuda.device(p1.device):
+            _lib.check(_lib.load().pdr_knn_points_grad(p1.data_ptr(), p2.data_ptr(), idx.data_ptr(), g.data_ptr(), B,
+                                                       n1, n2, K, g1.data_ptr(), g2.data_ptr(), _stream()),
+                       "knn_points_grad")
+        return g1, g2, None
+
+
+def knn_points(p1, p2, K, return_nn=False):
+    """pytorch3d.ops.knn.knn_points on dense equal-length clouds:
+    (B,n1,3), (B,n2,3) -> (dists (B,n1,K) f32 squared ascending, idx (B,n1,K) i64, nn (B,n1,K,3) | None).
+    With grad enabled and an input that requires it, `dists` (and `nn`, as a gather of p2) are differentiable."""
+    _req(p1, "p1", torch.float32)
+    _req(p2, "p2", torch.float32)
+    _same_device(p1, p2)
+    if p1.shape[2] != 3 or p2.shape[2] != 3:
+        raise RuntimeError("knn_points: only D=3 is built")
+    if torch.is_grad_enabled() and (p1.requires_grad or p2.requires_grad):
+        dists, idx = _KnnDists.apply(p1, p2, int(K))
+        nn = None
+        if return_nn:
+            B, n1, _ = p1.shape
+            safe = idx.clamp(min=0).reshape(B, n1 * int(K), 1).expand(-1, -1, 3)
+            nn = p2.gather(1, safe).reshape(B, n1, int(K), 3) * (idx >= 0).unsqueeze(-1)
+        return dists, idx, nn
+    return _knn_forward(p1, p2, K, return_nn)

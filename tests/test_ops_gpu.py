@@ -153,6 +153,45 @@ def test_knn_exact(cuda, B, n1, n2, K):
     assert np.array_equal(host(nn), gathered)
 
 
+@pytest.mark.parametrize("B,n1,n2,K", [(2, 300, 257, 1), (2, 128, 64, 8), (1, 10, 6, 8), (3, 2048, 2048, 1)])
+def test_knn_grad_vs_oracle(cuda, B, n1, n2, K):
+    """pdr_knn_points_grad through the C ABI == oracle (atomics: 1e-5 relative to the gradient scale)."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, n1, 3)).astype(np.float32)
+    y = rng.standard_normal((B, n2, 3)).astype(np.float32)
+    g = rng.standard_normal((B, n1, K)).astype(np.float32)
+    xt = torch.tensor(x, device=cuda, requires_grad=True)
+    yt = torch.tensor(y, device=cuda, requires_grad=True)
+    d, idx, _ = _ext.knn_points(xt, yt, K)
+    assert d.requires_grad and not idx.requires_grad
+    (d * torch.tensor(g, device=cuda)).sum().backward()
+    _, oi = O.knn(x, y, K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oi)
+    gx, gy = O.knn_grad(x, y, oi, g)
+    scale = max(1.0, float(np.abs(gy).max()))
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), gx, rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(yt.grad.cpu().numpy(), gy, rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_calc_cd_is_differentiable_like_the_reference_loss(cuda):
+    """train.py:518-533 back-propagates calc_cd; gradient == float64 brute-force Chamfer autograd."""
+    rng = np.random.default_rng(12)
+    out = rng.uniform(-0.5, 0.5, (2, 256, 3)).astype(np.float32)
+    gt = rng.uniform(-0.5, 0.5, (2, 300, 3)).astype(np.float32)
+    o = torch.tensor(out, device=cuda, requires_grad=True)
+    cd_p, cd_t = calc_cd(o, torch.tensor(gt, device=cuda))
+    (cd_t.sum() + 0.5 * cd_p.sum()).backward()
+    o64 = torch.tensor(out, dtype=torch.float64, requires_grad=True)
+    g64 = torch.tensor(gt, dtype=torch.float64)
+    dmat = ((g64.unsqueeze(2) - o64.unsqueeze(1)) ** 2).sum(-1)          # (B, n_gt, n_out)
+    d1, d2 = dmat.min(2).values, dmat.min(1).values
+    ref_t = d1.mean(1) + d2.mean(1)
+    ref_p = (d1.sqrt().mean(1) + d2.sqrt().mean(1)) / 2
+    (ref_t.sum() + 0.5 * ref_p.sum()).backward()
+    np.testing.assert_allclose(cd_t.detach().cpu().numpy(), ref_t.detach().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(o.grad.cpu().numpy(), o64.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
 def test_group_knn_layout(cuda):
     rr = rng(11)
     x = rr.uniform(-1, 1, (2, 64, 3)).astype(np.float32)

@@ -225,3 +225,25 @@ def test_gather_group_and_their_adjoints():
     np.testing.assert_allclose((g * w).sum(), (feats * O.gather_points_grad(w, idx, 50)).sum(), rtol=1e-4)
     w = rr.standard_normal(gg.shape).astype(np.float32)
     np.testing.assert_allclose((gg * w).sum(), (feats * O.group_points_grad(w, gidx, 50)).sum(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("n1,n2,K", [(40, 50, 1), (33, 20, 4), (10, 6, 8)])
+def test_knn_grad_is_the_adjoint_of_the_squared_distances(n1, n2, K):
+    """Oracle knn backward == autograd of sum(g * |x - y[idx]|^2) in float64 (pytorch3d backward, norm 2);
+    K > n2: padded slots (idx -1) contribute nothing."""
+    import torch
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, n1, 3)).astype(np.float32)
+    y = rng.standard_normal((2, n2, 3)).astype(np.float32)
+    g = rng.standard_normal((2, n1, K)).astype(np.float32)
+    _, idx = O.knn(x, y, K)
+    gx, gy = O.knn_grad(x, y, idx, g)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yt = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+    it = torch.tensor(idx)
+    valid = (it >= 0)
+    near = yt.gather(1, it.clamp(min=0).reshape(2, -1, 1).expand(-1, -1, 3)).reshape(2, n1, K, 3)
+    d = ((xt.unsqueeze(2) - near) ** 2).sum(-1)
+    (d * torch.tensor(g, dtype=torch.float64) * valid).sum().backward()
+    np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gy, yt.grad.numpy(), rtol=1e-5, atol=1e-5)
