@@ -15,7 +15,7 @@
 // boundaries, so the first chunk of the next tile is staged during the epilogue of the current one.
 // Register budget 128 (consumers: 64 accumulators, producers: one chunk in flight) = 4 waves / SIMD.
 //
-// Results are bit-identical to fused_layer_kernel: same k order per accumulator, same epilogue.
+// Results equal fused_layer_kernel up to fp32 summation order (the bias is the accumulators' initial value here).
 #include "pdr_common.h"
 
 #include <type_traits>
@@ -297,13 +297,15 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     const int col = n0 + (wc * CT + j) * 32 + il;
     bias_r[j] = (bias && col < Cout) ? bias[col] : 0.0f;
   }
+  // accumulators start at the bias: the epilogue has no add to do (every VALU instruction of an
+  // epilogue waits behind the other workgroup's MFMAs)
   f32x16 acc[RT][CT];
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < CT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_r[j];
 
   Cur cur{static_cast<int>(blockIdx.x), 0, 0, 0};
   for (int g = 0; g < G; ++g) {
@@ -332,56 +334,97 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
       const bool rows_full = nvalid == TM;   // uniform
-      // opaque copy: keeps the per-row store offsets from being hoisted out of the chunk loop
+      // opaque copies: keep the per-row store offsets from being hoisted out of the chunk loop
       // (64 live 64-bit addresses would spill)
       int il_e = il, hi_e = hi;
       asm volatile("" : "+v"(il_e), "+v"(hi_e));
+      long ldy_e = ldy;                       // same for the uniform row offsets (scalar registers)
+      asm volatile("" : "+s"(ldy_e));
+      const int osh = in.oadd ? __builtin_ctz(in.oadd_div) : 0;
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
         const int cl = (wc * CT + j) * 32 + il_e;
         const int col = n0 + cl;
         const bool colok = col < Cout;
-        const float bv = bias_r[j];
-        const bool relu_stat = col >= relu_col0;
+        const int c0 = n0 + (wc * CT + j) * 32;                  // first column of this 32-wide tile
         float s1 = 0.0f, s2 = 0.0f;
-        float* ybase = Y + row0 * ldy + col;
-        if (colok && in.oadd) {
-          const int osh = __builtin_ctz(in.oadd_div);
-          const float* ob = in.oadd + col;
+        if (rows_full) {
+          // ---- full row tile (the common case): stores = scalar row base + one per-lane offset,
+          // statistics without selects when the ReLU boundary does not cut this column tile
+          if (in.oadd) {
+            const float* ob = in.oadd + (colok ? col : 0);
+            if (osh >= 5) {
+              // K >= 32 neighbours per query: a 32-row MFMA tile belongs to ONE query row of `oadd`
 #pragma unroll
-          for (int i = 0; i < RT; ++i) {
+              for (int i = 0; i < RT; ++i) {
+                const float v = ob[((row0 + (wr * RT + i) * 32) >> osh) * in.oadd_ld];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int rl = min((wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e, nvalid - 1);
-              acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += v;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
+                  acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
+                }
             }
           }
-        }
-        if (colok) {
-          if (rows_full) {
+          const unsigned lane_off = static_cast<unsigned>(4 * hi_e * ldy + col) * 4u;   // bytes
+          const long row_bytes = ldy_e * 4;
+          const bool none_relu = c0 + 32 <= relu_col0, all_relu = c0 >= relu_col0;   // uniform
+          // MODE 0: no column of this tile takes the ReLU in its statistics, 1: all do, 2: the
+          // boundary cuts the tile (per-lane select)
+          auto store_tile = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+            const float lo = (MODE == 2 && col < relu_col0) ? -__builtin_inff() : 0.0f;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
+              // running row pointer (scalar adds only): rows 0,1,2,3, 8,9,10,11, 16.. of the MFMA tile
+              char* q = reinterpret_cast<char*>(Y + (row0 + (wr * RT + i) * 32) * ldy_e);
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
-                const float y = acc[i][j][r] + bv;
+                if (r > 0) q += ((r & 3) == 0 ? 5 : 1) * row_bytes;
+                const float y = acc[i][j][r];
 #ifndef PDR_LAB_NO_STORE
-                ybase[rl * ldy] = y;
+                *reinterpret_cast<float*>(q + lane_off) = y;
 #else
-                if (y == 123.456f) ybase[rl * ldy] = y;
+                if (y == 123.456f) *reinterpret_cast<float*>(q + lane_off) = y;
 #endif
-                const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+                const float f = MODE == 0 ? y : vmax(y, lo);
                 s1 += f;
                 s2 = __builtin_fmaf(f, f, s2);
               }
             }
-          } else {
+          };
+          if (colok) {
+            if (none_relu) store_tile(std::integral_constant<int, 0>());
+            else if (all_relu) store_tile(std::integral_constant<int, 1>());
+            else store_tile(std::integral_constant<int, 2>());
+          }
+        } else {
+          // ---- partial row tile (last tile of a batch element): per-row predicates
+          const bool relu_stat = col >= relu_col0;
+          float* ybase = Y + row0 * ldy + col;
+          if (colok && in.oadd) {
+            const float* ob = in.oadd + col;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int rl = min((wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e, nvalid - 1);
+                acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
+              }
+            }
+          }
+          if (colok) {
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
-                const float y = acc[i][j][r] + bv;
+                const float y = acc[i][j][r];
                 if (rl < nvalid) {
                   ybase[rl * ldy] = y;
                   const float f = relu_stat ? fmaxf(y, 0.0f) : y;
@@ -400,10 +443,14 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             red[wr][cl][1] = s2;
           }
         }
+        // (opaque: otherwise the 16-wide splat of the bias is kept live -- and spilled -- across
+        // the whole chunk loop instead of being rebuilt here with 16 moves)
+        float bj = bias_r[j];
+        asm volatile("" : "+v"(bj));
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = bj;
       }
       if (has_partial) {
         __syncthreads();   // E
@@ -458,7 +505,7 @@ bool launch_fused_layer_ws(int id, bool radd, const pdr_layer_in_t& in, int Cin,
     case 0: PDR_WS(2, 1, 4, 1, 16); return true;
     case 1: PDR_WS(2, 2, 4, 1, 16); return true;
     case 2: PDR_WS(1, 3, 4, 1, 32); return true;
-    case 3: PDR_WS(1, 5, 4, 1, 32); return true;
+    // case 3 (128 x 160: 80 accumulators) does not fit the 128-register budget: uniform-wave kernel
     case 4: PDR_WS(2, 2, 2, 2, 32); return true;
     case 5: PDR_WS(1, 2, 2, 2, 32); return true;
     default: return false;
