@@ -1,0 +1,86 @@
+"""H1 harness contract end to end (completion_eval.py:145-265) on one GPU: the HIP product path
+(fused network + graph-captured sampler + HIP Chamfer / EMD) against the SAME pipeline on the CPU over the
+oracle ops (reference-style eager `sampling` loop, layer-by-layer network), same weights, same CPU noise stream.
+Small network, T = 8, so the oracle side finishes in seconds."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.det_weights import fill_deterministic
+from tests.golden.tiny_config import small_fused_config
+from tests.oracle_backend import oracle_ops
+
+from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
+from point_diffusion_refinement_amd.pointnet2 import generation as G
+from point_diffusion_refinement_amd.pointnet2 import util
+from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedReverseSampler
+
+pytestmark = pytest.mark.gpu
+
+T, N, M = 8, 256, 384
+
+
+def _dataset(lo, hi):
+    idx = torch.arange(lo, hi)
+    gt = torch.stack([torch.rand(N, 3, generator=torch.Generator().manual_seed(500 + int(i))) * 2 - 1 for i in idx])
+    part = gt[:, :M // 2] * 0.95
+    cond = torch.cat([torch.cat([part, part * torch.tensor([1.0, 1.0, -1.0])], 1),
+                      torch.cat([torch.ones(hi - lo, M // 2, 1), -torch.ones(hi - lo, M // 2, 1)], 1)], 2)
+    return cond, idx % 16, gt
+
+
+def test_generate_and_evaluate_matches_the_cpu_oracle_pipeline():
+    cuda = torch.device("cuda:0")
+    dh = util.calc_diffusion_hyperparams(T, 1e-4, 0.02)
+    cfg = small_fused_config()
+    net_cpu = fill_deterministic(PointNet2CloudCondition(cfg), 31).eval()
+    net_gpu = fill_deterministic(PointNet2CloudCondition(cfg), 31).eval().to(cuda)
+    sampler = GraphedReverseSampler(FN.FusedCloudConditionNet(net_gpu), dh, noise='cpu', use_graph=True)
+
+    def gen_gpu(condition, label):
+        return sampler.sample((condition.shape[0], N, 3), condition, label)
+
+    def gen_cpu(condition, label):
+        util.set_noise_source('cpu')
+        with contextlib.redirect_stdout(io.StringIO()):
+            return util.sampling(net_cpu, (condition.shape[0], N, 3), dh, label=label, verbose=False,
+                                 condition=condition)
+
+    def data_gpu(lo, hi):
+        return tuple(t.to(cuda) for t in _dataset(lo, hi))
+
+    # 1 shape = 26 partial views -> batches of 16 + 10 (short last batch through the SAME captured graph is not
+    # possible: the sampler re-captures for the new batch size)
+    torch.manual_seed(123)
+    with torch.no_grad():
+        gen_a, rec_a, sum_a = G.generate_and_evaluate(gen_gpu, data_gpu, 1, batch_size=16, scale=1.0)
+    util.set_device(torch.device("cpu"))
+    torch.manual_seed(123)
+    try:
+        with oracle_ops(), torch.no_grad():
+            # pointnet2/emd.py asserts CUDA inputs (as the reference does): EMD of the CPU side comes
+            # straight from the oracle
+            gen_b, rec_b, _ = G.generate_and_evaluate(gen_cpu, _dataset, 1, batch_size=16, scale=1.0,
+                                                      compute_emd=False)
+    finally:
+        util.set_device(None)
+    from oracle import pdr_oracle as O
+    rec_b = rec_b.clone()
+    rec_b[:, 3] = torch.from_numpy(O.emd(gen_b.numpy(), (_dataset(0, 26)[2] / 2).numpy()))
+    sum_b = G.summarize(rec_b)
+    a, b = gen_a.cpu().numpy(), gen_b.numpy()
+    assert a.shape == (26, N, 3)
+    rel = np.abs(a - b) / (np.abs(b) + 1.0)
+    assert rel.max() < 1e-3 and (rel < 1e-4).mean() > 0.99, rel.max()
+    ra, rb = rec_a.cpu().numpy(), rec_b.numpy()
+    np.testing.assert_array_equal(ra[:, 4], rb[:, 4])                      # labels
+    np.testing.assert_allclose(ra[:, 0], rb[:, 0], rtol=2e-3)              # cd_t
+    np.testing.assert_allclose(ra[:, 1], rb[:, 1], rtol=2e-3)              # cd_p
+    np.testing.assert_allclose(ra[:, 3], rb[:, 3], rtol=5e-3)              # emd
+    assert np.abs(ra[:, 2] - rb[:, 2]).max() <= 2.0 / N + 1e-6             # F1: at most one point flips
+    for k in sum_b:
+        assert abs(sum_a[k] - sum_b[k]) <= 5e-3 * abs(sum_b[k]) + 1e-5, k
