@@ -50,6 +50,22 @@ def evaluate_batch(generate, condition, label, gt, scale=1.0, f1_threshold=1e-4,
     return generated, rec
 
 
+def refine_completion(refine_net, generated, condition, label, output_scale_factor, point_upsample_factor=1,
+                      include_displacement_center_to_final_output=False):
+    """Second stage of the paper (completion_eval.py:159-168, task 'refine_completion'): ONE forward of the
+    refinement network (include_t = False) predicts a displacement of the coarse cloud; with
+    point_upsample_factor f > 1 every coarse point emits f points (models/point_upsample_module.py:4-28).
+    (B,N,3) coarse -> (B, N f, 3)."""
+    from .models.point_upsample_module import point_upsample
+    refine_net.reset_cond_features()
+    displacement = refine_net(generated, condition, ts=None, label=label)
+    if point_upsample_factor > 1:
+        refined, _ = point_upsample(generated, displacement, point_upsample_factor,
+                                    include_displacement_center_to_final_output, output_scale_factor)
+        return refined
+    return generated + displacement * output_scale_factor
+
+
 def gather_records(records, group=None):
     """All ranks' (n_r, C) records concatenated in rank order -> (sum n_r, C) on every rank.
     Shards may have different lengths (last rank short): lengths are exchanged first and the

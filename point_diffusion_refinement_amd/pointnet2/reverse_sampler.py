@@ -42,18 +42,23 @@ class GraphedReverseSampler:
         self._key = None
 
     # ------------------------------------------------------------------ one step
-    def _step(self):
-        t = self._t                                   # (1,) int64 on device
-        ts = t.to(torch.float32).expand(self._x.shape[0])
-        eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
+    NOISE_AT_LAST_STEP = False     # util.sampling draws no noise at t = 0
+
+    def _timestep(self, t):
+        """Network time input of the step whose device counter is `t` ((1,) int64)."""
+        return t.to(torch.float32)
+
+    def _update(self, x, eps, t, z):
         # index_select keeps the lookup on the device (tensor[t] with a 0-d index would call .item())
         c_eps, sqrt_a, sigma = (tab.index_select(0, t) for tab in (self.c_eps, self.sqrt_alpha, self.sigma))
-        x = (self._x - c_eps * eps) / sqrt_a
-        if self.noise == 'device':
-            z = torch.randn_like(x)
-        else:
-            z = self._z
-        self._x.copy_(x + sigma * z)
+        return (x - c_eps * eps) / sqrt_a + sigma * z
+
+    def _step(self):
+        t = self._t                                   # (1,) int64 on device, counts down to 0
+        ts = self._timestep(t).expand(self._x.shape[0])
+        eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
+        z = torch.randn_like(self._x) if self.noise == 'device' else self._z
+        self._x.copy_(self._update(self._x, eps, t, z))
         self._t.sub_(1)
 
     def _prepare(self, size, condition, label):
@@ -131,8 +136,8 @@ class GraphedReverseSampler:
             self.net.sync_condition()                  # fused network: refresh its channel-last copies in place
 
     def _draw_cpu_noise(self):
-        # reference order: one draw per step with t > 0, none at t = 0
-        if self.noise == 'cpu' and self.remaining > 1:
+        # reference order: one draw per step with t > 0, none at t = 0 (FastDPM: every step)
+        if self.noise == 'cpu' and (self.remaining > 1 or self.NOISE_AT_LAST_STEP):
             self._z.copy_(torch.normal(0, 1, size=tuple(self._x.shape)))
         elif self.noise == 'cpu':
             self._z.zero_()
@@ -168,3 +173,57 @@ class GraphedReverseSampler:
         """Equivalent of util.sampling(net, size, dh, label=label, condition=condition)."""
         self.begin(size, condition, label, x_T)
         return self.finish()
+
+
+class GraphedFastSampler(GraphedReverseSampler):
+    """hipGraph-captured FastDPM loop (util_fastdpmv2.fast_sampling_function_v2 :455-476: VAR_sampling :307-381 /
+    STEP_sampling :384-452): S << T network calls at (fractional) times tau_i with the DDIM-style update
+        x <- x sqrt(a'/a) + ( (sqrt(1 - a' - s^2) - sqrt(1 - a) sqrt(a'/a)) eps + s z ),   a' := 1, s := 0 at the end.
+    The per-step constants are evaluated on the host exactly like the reference (float32 torch scalars), stored in
+    device tables indexed by the same down-counting device step counter as the DDPM loop."""
+
+    NOISE_AT_LAST_STEP = True      # _ddim_update draws std_normal on every step, also when sigma = 0
+
+    def __init__(self, net, diffusion_hyperparams, diffusion_config, length=50, sampling_method='var',
+                 schedule='quadratic', kappa=0.0, noise='device', use_graph=True):
+        from . import util_fastdpmv2 as F
+        super().__init__(net, diffusion_hyperparams, noise=noise, use_graph=use_graph)
+        dh = diffusion_hyperparams
+        assert sampling_method in ('var', 'step') and schedule in ('quadratic', 'linear') and 0.0 <= kappa <= 1.0
+        if sampling_method == 'var':
+            eta = F.get_VAR_noise(length, diffusion_config, schedule)
+            steps = F._precompute_VAR_steps(dh, eta)
+            gamma_bar = F._gamma_bar(eta)
+            S = len(gamma_bar)
+            alpha_of = lambda i: gamma_bar[S - 1 - i]
+            assert abs(steps[-1]) < 0.1
+        else:
+            steps = sorted(list(F.get_STEP_step(length, diffusion_config, schedule)), reverse=True)
+            abar = dh["Alpha_bar"].cpu()
+            alpha_of = lambda i: abar[steps[i]]
+            assert steps[-1] == 0
+        n = len(steps)
+        scale, c, sig, tau = [], [], [], []
+        for i in range(n):
+            a_cur = alpha_of(i)
+            if i == n - 1:
+                a_next, sigma = torch.tensor(1.0), torch.tensor(0.0)
+            else:
+                a_next = alpha_of(i + 1)
+                sigma = kappa * torch.sqrt((1 - a_next) / (1 - a_cur) * (1 - a_cur / a_next))
+            scale.append(torch.sqrt(a_next / a_cur))
+            c.append(torch.sqrt(1 - a_next - sigma ** 2) - torch.sqrt(1 - a_cur) * torch.sqrt(a_next / a_cur))
+            sig.append(torch.as_tensor(sigma, dtype=torch.float32))
+            tau.append((steps[i] * torch.ones((1,)))[0])           # float32, as `tau * torch.ones((B,))`
+        # the device counter runs S-1 ... 0: entry t of a table belongs to step i = S-1-t
+        rev = lambda xs: torch.stack([torch.as_tensor(v, dtype=torch.float32) for v in xs[::-1]]).to(self.device)
+        self.f_scale, self.f_c, self.f_sigma, self.f_tau = rev(scale), rev(c), rev(sig), rev(tau)
+        self.T = n
+
+    def _timestep(self, t):
+        return self.f_tau.index_select(0, t)
+
+    def _update(self, x, eps, t, z):
+        scale, c, sigma = (tab.index_select(0, t) for tab in (self.f_scale, self.f_c, self.f_sigma))
+        x = x * scale
+        return x + (c * eps + sigma * z)

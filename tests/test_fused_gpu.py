@@ -194,3 +194,35 @@ def test_fused_layer_vector_staging(cuda, P, Cin, Cout, rpb):
         assert _rel(Y[:, :Cout].double(), ref) < 2e-5
         got = part.view(B, tpb, Cout, 2).double().sum(1)
         assert _rel(got[..., 0], ref.view(B, rpb, Cout).sum(1)) < 1e-4
+
+
+@pytest.mark.parametrize("method,schedule,kappa", [("var", "quadratic", 0.5), ("step", "linear", 0.0)])
+def test_graphed_fast_sampler_matches_fastdpm_reference_loop(cuda, method, schedule, kappa):
+    """Config-5 sampler: graph-captured FastDPM loop (fractional time steps, DDIM-style update) == the
+    reference-style eager loop of util_fastdpmv2 on the same CPU noise stream."""
+    import contextlib, io
+    from point_diffusion_refinement_amd.pointnet2 import util_fastdpmv2 as F
+    from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG
+    from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedFastSampler
+    net, fused = _pair(small_fused_config(), 23, cuda)
+    dh = util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG)
+    g = torch.Generator().manual_seed(8)
+    cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
+    label = torch.tensor([3, 11], device=cuda)
+    util.set_device(cuda)
+    util.set_noise_source('cpu')
+    try:
+        torch.manual_seed(99)
+        with contextlib.redirect_stdout(io.StringIO()):
+            want = F.fast_sampling_function_v2(net, (2, 256, 3), dh, DIFFUSION_CONFIG, length=8,
+                                               sampling_method=method, schedule=schedule, kappa=kappa, label=label,
+                                               verbose=False, condition=cond)
+    finally:
+        util.set_device(None)
+    for use_graph in (False, True):
+        sampler = GraphedFastSampler(fused, dh, DIFFUSION_CONFIG, length=8, sampling_method=method,
+                                     schedule=schedule, kappa=kappa, noise='cpu', use_graph=use_graph)
+        torch.manual_seed(99)
+        got = sampler.sample((2, 256, 3), cond, label)
+        rel = ((got - want).abs() / (want.abs() + 1.0))
+        assert rel.max() < 1e-3 and (rel < 1e-4).float().mean() > 0.99, (use_graph, rel.max())

@@ -84,3 +84,30 @@ def test_generate_and_evaluate_matches_the_cpu_oracle_pipeline():
     assert np.abs(ra[:, 2] - rb[:, 2]).max() <= 2.0 / N + 1e-6             # F1: at most one point flips
     for k in sum_b:
         assert abs(sum_a[k] - sum_b[k]) <= 5e-3 * abs(sum_b[k]) + 1e-5, k
+
+
+def test_refine_completion_with_upsampling_matches_the_cpu_oracle_pipeline():
+    """Config-5 second stage (completion_eval.py:159-168): refinement forward (include_t False) + point_upsample
+    x4, then Chamfer on the upsampled clouds: HIP path vs the same modules over the oracle ops on the CPU."""
+    from tests.golden.tiny_config import tiny_pointnet_config
+    from point_diffusion_refinement_amd.pointnet2.chamfer_loss_new import calc_cd
+    cuda = torch.device("cuda:0")
+    # (the constructor rewrites hparams['out_dim'] in place like the reference, :240-244: one dict per network)
+    mk = lambda: PointNet2CloudCondition(tiny_pointnet_config(include_t=False, point_upsample_factor=4))
+    net_cpu = fill_deterministic(mk(), 41).eval()
+    net_gpu = fill_deterministic(mk(), 41).eval().to(cuda)
+    cond, label, gt = _dataset(0, 4)
+    coarse = gt + 0.02 * torch.randn(gt.shape, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        fine_gpu = G.refine_completion(net_gpu, coarse.to(cuda), cond.to(cuda), label.to(cuda), 0.001, 4)
+        cd_gpu = calc_cd(fine_gpu, gt.to(cuda))[1]
+        with oracle_ops():
+            fine_cpu = G.refine_completion(net_cpu, coarse, cond, label, 0.001, 4)
+            cd_cpu = calc_cd(fine_cpu, gt)[1]
+    assert fine_gpu.shape == (4, 4 * N, 3)
+    # the displacement is scaled by 1e-3: compare it, not the (coarse-dominated) sum
+    d_gpu = (fine_gpu.cpu() - coarse.repeat_interleave(4, 1)).numpy()
+    d_cpu = (fine_cpu - coarse.repeat_interleave(4, 1)).numpy()
+    assert np.abs(d_cpu).max() > 0
+    np.testing.assert_allclose(d_gpu, d_cpu, rtol=2e-2, atol=2e-3 * np.abs(d_cpu).max())
+    np.testing.assert_allclose(cd_gpu.cpu().numpy(), cd_cpu.numpy(), rtol=1e-4)
