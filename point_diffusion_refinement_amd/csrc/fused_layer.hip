@@ -562,31 +562,45 @@ __global__ __launch_bounds__(1024) void gn_fold_kernel(FoldPart p0, FoldPart p1,
   extern __shared__ __attribute__((aligned(16))) double cs[];   // [C][2]
   __shared__ double red[32][32][2];
   const int b = blockIdx.x;
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double* redf = &red[0][0][0];   // [1024][2]
   int coff = 0;
   for (int part = 0; part < 2; ++part) {
     const FoldPart p = part == 0 ? p0 : p1;
     if (!p.partial) continue;
-    for (int c0 = 0; c0 < p.C; c0 += 32) {
+    // W channels x (1024 / W) tile slices per pass: ONE pass (two barriers) for C <= 1024 instead of
+    // one per 32 channels -- the kernel is barrier / latency bound, not bandwidth bound
+    int W = 32;
+    while (W < p.C && W < 1024) W <<= 1;
+    const int nsl = 1024 / W;
+    const int cl = threadIdx.x & (W - 1), sl = threadIdx.x / W;
+    for (int c0 = 0; c0 < p.C; c0 += W) {
       const int c = c0 + cl;
       double s1 = 0.0, s2 = 0.0;
       if (c < p.C) {
         const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + c) * 2;
-        for (int t = sl; t < p.tiles_per_batch; t += 32) {
-          const float2 v = *reinterpret_cast<const float2*>(q + static_cast<long>(t) * p.ldp * 2);
-          s1 += v.x;
-          s2 += v.y;
+        for (int t = sl; t < p.tiles_per_batch; t += nsl * 8) {
+          float2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int tt = t + nsl * u;
+            v[u] = tt < p.tiles_per_batch ? *reinterpret_cast<const float2*>(q + static_cast<long>(tt) * p.ldp * 2)
+                                          : make_float2(0.0f, 0.0f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            s1 += v[u].x;
+            s2 += v[u].y;
+          }
         }
       }
-      red[sl][cl][0] = s1;
-      red[sl][cl][1] = s2;
+      redf[threadIdx.x * 2 + 0] = s1;
+      redf[threadIdx.x * 2 + 1] = s2;
       __syncthreads();
       if (sl == 0 && c < p.C) {
         double a1 = 0.0, a2 = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-          a1 += red[k][cl][0];
-          a2 += red[k][cl][1];
+        for (int k = 0; k < nsl; ++k) {
+          a1 += redf[(k * W + cl) * 2 + 0];
+          a2 += redf[(k * W + cl) * 2 + 1];
         }
         cs[(coff + c) * 2 + 0] = a1 * p.mult;
         cs[(coff + c) * 2 + 1] = a2 * p.mult;

@@ -487,6 +487,7 @@ namespace pdr {
 bool launch_fused_layer_ws(int id, bool radd, const pdr_layer_in_t& in, int Cin, const float* Wt, int ldw,
                            const float* bias, int Cout, float* Y, int ldy, float* partial, int relu_col0,
                            int n_row_tiles, int ncol, hipStream_t s) {
+  if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   const long cap = (512 + ncol - 1) / ncol;
