@@ -23,11 +23,12 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // W quads: moved as values (float4 struct copies stay memcpy)
 
 #ifdef PDR_LAB_TRACE
 // development probe (tools/lab): per-chunk timestamps of one consumer and one producer wave of one workgroup
-__device__ unsigned long long pdr_lab_trace[2][4096];
+__device__ unsigned long long pdr_lab_trace[3][4096];
 #define PDR_T(role, slot)                                                                   \
   do {                                                                                      \
     if (trace_on && (threadIdx.x & 63) == 0 && (slot) < 4096)                               \
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
   __shared__ float As[2][KC][TM + 1];
   __shared__ __attribute__((aligned(16))) float Bs[2][KC][TN];
   __shared__ float red[WR][TN][2];
+  __shared__ int epi_ticket;          // consumer waves that finished the statistics of a tile (4 per tile)
+  // per consumer wave: half of a 32 x 32 accumulator tile, row-major, for 16-byte coalesced stores
+  __shared__ __attribute__((aligned(16))) float Tt[4][16][36];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
                        static_cast<int>(gridDim.x);
   const int G = my_tiles * nch;
   const bool has_partial = partial != nullptr;
+  if (tid == 0) epi_ticket = 0;       // ordered before its first use by the barrier B(0)
 #ifdef PDR_LAB_TRACE
   const bool trace_on = blockIdx.x == 37 % gridDim.x && blockIdx.y == 0 && (wave == 0 || wave == 4 || wave == 6);
 #endif
@@ -265,7 +270,6 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // LATENCY (not its issue cost) is what can delay the barrier: next to two MFMA-bound waves a
     // VALU instruction waits ~a whole MFMA issue slot.
     Cur co{static_cast<int>(blockIdx.x), 0, 0, 0};
-    bool prev_last = false;
     fetch(co);
     for (int g = 0; g < G; ++g) {
       PDR_T(1, 4 * g + 0);
@@ -275,15 +279,11 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 #endif
       commit(g & 1);
       PDR_T(1, 4 * g + 1);
-      const bool last = last_of_tile(co);
       advance(co, g + 1 < G);
       fetch(co);                                    // past the end: re-reads the last chunk
       PDR_T(1, 4 * g + 2);
-      if (prev_last && has_partial) __syncthreads();   // E: pairs with the consumers' stats barrier
       __syncthreads();                                 // B(g): stage g full, stage g+1 free
-      prev_last = last;
     }
-    if (has_partial) __syncthreads();                  // E of the last tile
     return;
   }
 
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       const bool rows_full = nvalid == TM;   // uniform
       // opaque copies: keep the per-row store offsets from being hoisted out of the chunk loop
       // (64 live 64-bit addresses would spill)
-      int il_e = il, hi_e = hi;
-      asm volatile("" : "+v"(il_e), "+v"(hi_e));
+      int il_e = il, hi_e = hi, lane_e = lane;
+      asm volatile("" : "+v"(il_e), "+v"(hi_e), "+v"(lane_e));
       long ldy_e = ldy;                       // same for the uniform row offsets (scalar registers)
       asm volatile("" : "+s"(ldy_e));
       const int osh = in.oadd ? __builtin_ctz(in.oadd_div) : 0;
@@ -376,65 +376,94 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           const bool none_relu = c0 + 32 <= relu_col0, all_relu = c0 >= relu_col0;   // uniform
           // MODE 0: no column of this tile takes the ReLU in its statistics, 1: all do, 2: the
           // boundary cuts the tile (per-lane select)
-          auto store_tile = [&](auto mode) {
+          // Stores: the MFMA layout has a lane per COLUMN, i.e. 64 dword stores per wave and tile, and
+          // the epilogue is store-issue bound (~110 cycles per wave store).  With a 16-byte aligned
+          // output each half tile goes through LDS (8 ds_write_b32 + 2 ds_read_b128 per lane) and
+          // leaves as 2 dwordx4 stores covering 8 full 128-byte rows each: 4x fewer store instructions.
+          const bool wide_store = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;   // uniform
+          const int rr = lane_e >> 3, c4 = (lane_e & 7) * 4;
+          const bool col4ok = c0 + c4 + 3 < ldy;
+          unsigned toff = static_cast<unsigned>(rr * ldy + c0 + c4) * 4u;
+          asm volatile("" : "+v"(toff));   // not hoistable: 64-bit store addresses per (tile, half) would spill
+          auto store_tile = [&](auto mode, auto wide) {
             constexpr int MODE = decltype(mode)::value;
+            constexpr bool WIDE = decltype(wide)::value;
             const float lo = (MODE == 2 && col < relu_col0) ? -__builtin_inff() : 0.0f;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
               // running row pointer (scalar adds only): rows 0,1,2,3, 8,9,10,11, 16.. of the MFMA tile
               char* q = reinterpret_cast<char*>(Y + (row0 + (wr * RT + i) * 32) * ldy_e);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                if (r > 0) q += ((r & 3) == 0 ? 5 : 1) * row_bytes;
-                const float y = acc[i][j][r];
-#ifndef PDR_LAB_NO_STORE
-                *reinterpret_cast<float*>(q + lane_off) = y;
-#else
-                if (y == 123.456f) *reinterpret_cast<float*>(q + lane_off) = y;
-#endif
-                const float f = MODE == 0 ? y : vmax(y, lo);
-                s1 += f;
-                s2 = __builtin_fmaf(f, f, s2);
+              for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                  const float y = acc[i][j][8 * h + r8];
+                  if (WIDE) {
+                    Tt[wave][8 * (r8 >> 2) + (r8 & 3) + 4 * hi_e][il_e] = y;
+                  } else {
+                    if (h + r8 > 0) q += ((r8 & 3) == 0 ? 5 : 1) * row_bytes;
+                    if (colok) *reinterpret_cast<float*>(q + lane_off) = y;
+                  }
+                }
+                // statistics: plain scalar adds / fmas (v_pk_* forms measured slower next to MFMAs)
+                if (colok) {
+#pragma unroll
+                  for (int r8 = 0; r8 < 8; ++r8) {
+                    const float y = acc[i][j][8 * h + r8];
+                    const float f = MODE == 0 ? y : vmax(y, lo);
+                    s1 += f;
+                    s2 = __builtin_fmaf(f, f, s2);
+                  }
+                }
+                if (WIDE) {
+                  const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Tt[wave][rr][c4]);
+                  const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Tt[wave][rr + 8][c4]);
+                  if (col4ok) {
+                    char* qh = q + (16 * h) * row_bytes;
+                    *reinterpret_cast<f32x4*>(qh + toff) = v0;
+                    *reinterpret_cast<f32x4*>(qh + 8 * row_bytes + toff) = v1;
+                  }
+                }
               }
             }
           };
-          if (colok) {
-            if (none_relu) store_tile(std::integral_constant<int, 0>());
-            else if (all_relu) store_tile(std::integral_constant<int, 1>());
-            else store_tile(std::integral_constant<int, 2>());
+          // (all lanes take part: a lane's 16-byte column group is independent of its own column)
+          using M0 = std::integral_constant<int, 0>;
+          using M1 = std::integral_constant<int, 1>;
+          using M2 = std::integral_constant<int, 2>;
+          if (wide_store) {
+            if (none_relu) store_tile(M0(), std::true_type());
+            else if (all_relu) store_tile(M1(), std::true_type());
+            else store_tile(M2(), std::true_type());
+          } else {
+            store_tile(M2(), std::false_type());   // unaligned output: scalar stores, general statistics
           }
         } else {
           // ---- partial row tile (last tile of a batch element): per-row predicates
           const bool relu_stat = col >= relu_col0;
           float* ybase = Y + row0 * ldy + col;
-          if (colok && in.oadd) {
-            const float* ob = in.oadd + col;
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int rl = min((wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e, nvalid - 1);
-                acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
-              }
-            }
-          }
+          // (rare path: one row at a time keeps its register footprint small)
+          const float* ob = in.oadd ? in.oadd + (colok ? col : 0) : nullptr;
           if (colok) {
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
-                const float y = acc[i][j][r];
                 if (rl < nvalid) {
+                  float y = acc[i][j][r];
+                  if (ob) y += ob[((row0 + rl) >> osh) * in.oadd_ld];
                   ybase[rl * ldy] = y;
                   const float f = relu_stat ? fmaxf(y, 0.0f) : y;
                   s1 += f;
                   s2 = __builtin_fmaf(f, f, s2);
                 }
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
           }
         }
+        PDR_T(2, 8 * (g / nch) + j);
         if (has_partial) {
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
@@ -452,18 +481,30 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = bj;
       }
+      PDR_T(2, 8 * (g / nch) + 6);
       if (has_partial) {
-        __syncthreads();   // E
-        if (tid < TN && n0 + tid < Cout) {
-          float s1 = 0.0f, s2 = 0.0f;
+        // Cross-wave fold of the statistics WITHOUT a workgroup barrier (the producers would have to
+        // join it, and they are busy staging the next chunk): every consumer wave takes a ticket
+        // after its LDS writes; the wave drawing the last ticket of this tile sums the WR rows (fixed
+        // order w = 0..WR-1, deterministic) and writes the tile's partial row.
+        int ticket = 0;
+        if (lane == 0)
+          ticket = __hip_atomic_fetch_add(&epi_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if ((ticket & 3) == 3) {
+          for (int c = lane; c < TN; c += 64) {
+            if (n0 + c < Cout) {
+              float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-          for (int w = 0; w < WR; ++w) {
-            s1 += red[w][tid][0];
-            s2 += red[w][tid][1];
+              for (int w = 0; w < WR; ++w) {
+                s1 += red[w][c][0];
+                s2 += red[w][c][1];
+              }
+              float* o = partial + (static_cast<long>(tile) * Cout + n0 + c) * 2;
+              o[0] = s1;
+              o[1] = s2;
+            }
           }
-          float* o = partial + (static_cast<long>(tile) * Cout + n0 + tid) * 2;
-          o[0] = s1;
-          o[1] = s2;
         }
       }
     }
@@ -476,7 +517,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 
 #ifdef PDR_LAB_TRACE
 extern "C" int pdr_lab_trace_read(unsigned long long* dst) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pdr_lab_trace), sizeof(unsigned long long) * 2 * 4096) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pdr_lab_trace), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
 }
 #endif
 
