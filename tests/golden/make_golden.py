@@ -176,6 +176,15 @@ def metrics():
     save("metrics.npz", **out)
 
 
+def mirror():
+    """data_utils/mirror_partial.py:22-38 on a small cloud (FPS through the oracle stand-in)."""
+    from data_utils.mirror_partial import mirror_and_concat
+    g = torch.Generator().manual_seed(17)
+    partial = torch.rand(2, 160, 3, generator=g) * 2 - 1
+    both, a, b = quiet(mirror_and_concat, partial, axis=2, num_points=[100, 256])
+    save("mirror.npz", partial=partial, both=both, down100=a, down256=b)
+
+
 def state_dict_keys():
     from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
     net = PointNet2CloudCondition(R.load_config()['pointnet_config'])
@@ -192,4 +201,5 @@ if __name__ == "__main__":
     network()
     schedules()
     metrics()
+    mirror()
     state_dict_keys()

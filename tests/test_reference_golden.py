@@ -233,6 +233,17 @@ def test_metrics_python_surface(be):
 
 
 # ----------------------------------------------------------------- host-only goldens
+def test_mirror_and_concat_preprocessing(be):
+    """data_utils/mirror_partial.py:22-38 (producer of the 3072-point, 4-channel condition clouds): bit-exact --
+    the only arithmetic is a sign flip; the rest is FPS index order and a row gather."""
+    from point_diffusion_refinement_amd.pointnet2.data_utils.mirror_partial import mirror_and_concat
+    g = gold("mirror.npz")
+    with be.ops():
+        both, a, b = mirror_and_concat(be.to(torch.from_numpy(g["partial"])), axis=2, num_points=[100, 256])
+    for got, key in ((both, "both"), (a, "down100"), (b, "down256")):
+        np.testing.assert_array_equal(got.cpu().numpy(), g[key])
+
+
 def test_diffusion_hyperparameters_and_fastdpm_schedules():
     g = gold("schedules.npz")
     cfg = {"T": 1000, "beta_0": 1e-4, "beta_T": 0.02}
