@@ -180,6 +180,12 @@ typedef struct {
   const float *gV0;
   int g_ldv;
   int g_nsrc;
+  /* Row index (relative to ptr, i.e. over all batch elements) of an ALL-ZERO row of the table, or -1.
+   * With it (and gV0 - gV a small non-negative offset inside one allocation) empty balls are read as
+   * "zero neighbour row + gV0 row" by plain address arithmetic; the wave-specialised kernel needs it
+   * whenever gcnt is given. */
+  int g_zrow;
+  int g_reserved;
 } pdr_seg_t;
 
 typedef struct {

@@ -58,7 +58,7 @@ SIGNATURES = {
 
 class Seg(_c.Structure):
     _fields_ = [("ptr", _P), ("C", _I), ("ld", _I), ("row_div", _I), ("gV", _P), ("gV0", _P), ("g_ldv", _I),
-                ("g_nsrc", _I)]
+                ("g_nsrc", _I), ("g_zrow", _I), ("g_reserved", _I)]
 
 
 class LayerIn(_c.Structure):

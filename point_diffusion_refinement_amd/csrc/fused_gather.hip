@@ -379,6 +379,10 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
   if (rows_per_batch % K != 0 || (counts && !V0) || (s1 && !r1) || (s2 && !r2)) return PDR_EINVAL;
   const int c4 = (Cout + 3) & ~3;
   if (ldu % 4 || ldv % 4 || ldu < c4 || ldv < c4 || (Y && (ldy % 4 || ldy < c4))) return PDR_EINVAL;
+  // rows are moved as float4: every base pointer (possibly offset to a column sub-range) 16-B aligned
+  auto al = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  if (!al(U) || !al(V) || (V0 && !al(V0)) || (Y && !al(Y)) || (r1 && !al(r1)) || (r2 && !al(r2)))
+    return PDR_EINVAL;
   const int tpb = (rows_per_batch + 127) / 128;
   const dim3 grid(static_cast<unsigned>(B) * tpb);
   hipStream_t st = pdr::as_stream(stream);

@@ -794,8 +794,9 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     const char* e = getenv("PDR_FUSED_WS");   // tuning knob: PDR_FUSED_WS=0 selects the uniform-wave kernel
     return !(e && e[0] == '0');
   }();
-  if (use_ws && vec && !gath &&
-      pdr::launch_fused_layer_ws(t.id, radd, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt, ncol, s))
+  if (use_ws && vec &&
+      pdr::launch_fused_layer_ws(t.id, radd, gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt,
+                                 ncol, s))
     return pdr::check_launch();
 #define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC, GATH)                                            \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC, GATH>), grid, dim3(256), 0, s, \

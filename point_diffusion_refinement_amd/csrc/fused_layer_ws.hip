@@ -53,7 +53,7 @@ __device__ __forceinline__ float vmax(float a, float b) {
   return r;
 }
 
-template <int RT, int CT, int WR, int WC, int KC, bool RADD>
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool GATH = false>
 __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
@@ -143,8 +143,16 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           r_off[i] = static_cast<unsigned>((vr0 + VSTEP * i) * in.rseg.ld + 4 * vc4) * 4u;
       }
     }
+    // GATHERED sources (first conv of a grouped block consumed without materialising it, see
+    // pdr_gather_add): x[p] = U[b, idx[p]] + V[p / K]; an empty ball reads the table's zero row + V0.
+    // Per tile: this thread's neighbour indices (-1 = empty ball); per (tile, segment): byte offsets.
+    int g_idx[GATH ? APT4 : 1];
+    unsigned v_off[GATH ? APT4 : 1];
+    int g_tile = -1;
+    const int gsh = GATH ? __builtin_ctz(in.gK) : 0;
+    bool Rgath = false;                                // chunk in flight comes from a gathered segment
     // one chunk in registers (plain arrays: as members of a struct one W quad ended up in scratch)
-    float4 Rrv[APT4], Rrrv[RADD ? APT4 : 1];
+    float4 Rrv[APT4], Rrrv[RADD ? APT4 : 1], Rrv2[GATH ? APT4 : 1];
     f32x4 Rrw[WPT4];
     float Rps[4], Rph[4], Rpa[4];
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
@@ -160,17 +168,47 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       const float* sc_b = (in.scale ? in.scale + static_cast<long>(b) * ss_ld : k_ones) + c.cbase + c.ks;
       const float* sh_b = (in.shift ? in.shift + static_cast<long>(b) * ss_ld : k_zeros) + c.cbase + c.ks;
       const float* ad_b = (in.add ? in.add + static_cast<long>(b) * in.add_ld : k_zeros) + c.cbase + c.ks;
+      const bool f_g = GATH && seg.gV != nullptr;               // uniform
+      if constexpr (GATH) {
+        if (c.tile != g_tile) {                                  // uniform: first chunk of a tile
+          g_tile = c.tile;
+          off_sg = -1;
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) {
+            const long p = row0 + min(vr0 + VSTEP * i, nvalid - 1);
+            const int id = in.gidx[p];
+            const int cnt = in.gcnt ? in.gcnt[p >> gsh] : 1;
+            g_idx[i] = cnt <= 0 ? -1 : id;
+          }
+        }
+      }
       // every load = uniform base (scalar registers) + 32-bit per-thread byte offset
-      const char* ab = reinterpret_cast<const char*>(seg.ptr + (row0 >> shift) * seg.ld + c.ks);
+      const char* ab = reinterpret_cast<const char*>(
+          seg.ptr + (f_g ? static_cast<long>(b) * seg.g_nsrc : (row0 >> shift)) * seg.ld + c.ks);
+      const int zrow = f_g ? seg.g_zrow - b * seg.g_nsrc : 0;    // the zero row, relative to this cloud
+      const int v0d = (f_g && seg.gV0) ? static_cast<int>(seg.gV0 - seg.gV) : 0;
       const char* wb = reinterpret_cast<const char*>(Wt + static_cast<long>(c.cbase + c.ks) * ldw + n0);
-      unsigned ao[APT4], ro[RADD ? APT4 : 1], wo[WPT4], po[4];
+      unsigned ao[APT4], ro[RADD ? APT4 : 1], wo[WPT4], po[4], vo[GATH ? APT4 : 1];
       if (Rkmax == KC && nvalid == TM) {
         // ---- fast path (uniform): the precomputed per-thread offsets
         if (off_sg != c.sg) {
           off_sg = c.sg;
 #pragma unroll
-          for (int i = 0; i < APT4; ++i)
-            a_off[i] = static_cast<unsigned>(((vr0 + VSTEP * i) >> shift) * seg.ld + 4 * vc4) * 4u;
+          for (int i = 0; i < APT4; ++i) {
+            int row = (vr0 + VSTEP * i) >> shift;
+            if constexpr (GATH) {
+              if (f_g) {
+                row = g_idx[i] < 0 ? zrow : g_idx[i];
+                v_off[i] = static_cast<unsigned>(((vr0 + VSTEP * i) >> gsh) * seg.g_ldv + 4 * vc4 +
+                                                 (g_idx[i] < 0 ? v0d : 0)) * 4u;
+              }
+            }
+            a_off[i] = static_cast<unsigned>(row * seg.ld + 4 * vc4) * 4u;
+          }
+        }
+        if constexpr (GATH) {
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) vo[i] = v_off[i];
         }
         Rcvalid = 4;
 #pragma unroll
@@ -194,7 +232,14 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
         for (int i = 0; i < APT4; ++i) {
           // rows beyond nvalid re-read the tile's last row; masked in the epilogue
           const int r = min(vr0 + VSTEP * i, nvalid - 1);
-          ao[i] = static_cast<unsigned>((r >> shift) * seg.ld + clc) * 4u;
+          int row = r >> shift;
+          if constexpr (GATH) {
+            if (f_g) {
+              row = g_idx[i] < 0 ? zrow : g_idx[i];
+              vo[i] = static_cast<unsigned>((r >> gsh) * seg.g_ldv + clc + (g_idx[i] < 0 ? v0d : 0)) * 4u;
+            }
+          }
+          ao[i] = static_cast<unsigned>(row * seg.ld + clc) * 4u;
           if constexpr (RADD) ro[i] = static_cast<unsigned>(r * in.rseg.ld + clc) * 4u;
         }
         const int nmax = ldw - n0 - 4;   // last in-row float4 offset
@@ -213,6 +258,14 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       }
 #pragma unroll
       for (int i = 0; i < APT4; ++i) Rrv[i] = *reinterpret_cast<const float4*>(ab + ao[i]);
+      if constexpr (GATH) {
+        Rgath = f_g;
+        if (f_g) {
+          const char* vb = reinterpret_cast<const char*>(seg.gV + (row0 >> gsh) * seg.g_ldv + c.ks);
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) Rrv2[i] = *reinterpret_cast<const float4*>(vb + vo[i]);
+        }
+      }
       if constexpr (RADD) {
         const char* rb = reinterpret_cast<const char*>(in.rseg.ptr + row0 * in.rseg.ld + c.cbase + c.ks);
 #pragma unroll
@@ -233,7 +286,12 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
         constexpr bool MASKED = decltype(masked)::value, PRE = decltype(pre)::value, ADD = decltype(add)::value;
 #pragma unroll
         for (int i = 0; i < APT4; ++i) {
-          const float x[4] = {Rrv[i].x, Rrv[i].y, Rrv[i].z, Rrv[i].w};
+          float x[4] = {Rrv[i].x, Rrv[i].y, Rrv[i].z, Rrv[i].w};
+          if constexpr (GATH) {
+            if (Rgath) {   // uniform: neighbour row + query row
+              x[0] += Rrv2[i].x; x[1] += Rrv2[i].y; x[2] += Rrv2[i].z; x[3] += Rrv2[i].w;
+            }
+          }
           float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           if constexpr (RADD) {
             q[0] = Rrrv[i].x; q[1] = Rrrv[i].y; q[2] = Rrrv[i].z; q[3] = Rrrv[i].w;
@@ -382,7 +440,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           // leaves as 2 dwordx4 stores covering 8 full 128-byte rows each: 4x fewer store instructions.
           const bool wide_store = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;   // uniform
           const int rr = lane_e >> 3, c4 = (lane_e & 7) * 4;
-          const bool col4ok = c0 + c4 + 3 < ldy;
+          // only the (4-padded) output columns: Y may be a column window of a wider row
+          const bool col4ok = c0 + c4 < ((Cout + 3) & ~3);
           unsigned toff = static_cast<unsigned>(rr * ldy + c0 + c4) * 4u;
           asm volatile("" : "+v"(toff));   // not hoistable: 64-bit store addresses per (tile, half) would spill
           auto store_tile = [&](auto mode, auto wide) {
@@ -525,10 +584,24 @@ namespace pdr {
 
 // Launches the wave-specialised kernel for tile variant `id` (pick_tile() of fused_layer.hip).
 // Returns false when the variant has no wave-specialised instantiation.
-bool launch_fused_layer_ws(int id, bool radd, const pdr_layer_in_t& in, int Cin, const float* Wt, int ldw,
-                           const float* bias, int Cout, float* Y, int ldy, float* partial, int relu_col0,
-                           int n_row_tiles, int ncol, hipStream_t s) {
+bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
+                           int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
+                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s) {
   if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
+  if (gath) {
+    // gathered sources here: plain residual only; empty balls through the table's zero row and a V0
+    // that sits a small non-negative offset behind V (one allocation)
+    if (radd || in.rseg.gV) return false;
+    for (int sg = 0; sg < in.n_seg; ++sg) {
+      const pdr_seg_t& g = in.seg[sg];
+      if (!g.gV) continue;
+      if (in.gcnt) {
+        if (g.g_zrow < 0 || !g.gV0) return false;
+        const long d = g.gV0 - g.gV;
+        if (d < 0 || d >= (1L << 28)) return false;
+      }
+    }
+  }
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   const long cap = (512 + ncol - 1) / ncol;
@@ -536,7 +609,10 @@ bool launch_fused_layer_ws(int id, bool radd, const pdr_layer_in_t& in, int Cin,
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS(RT, CT, WR, WC, KC)                                                                      \
   do {                                                                                                  \
-    if (radd)                                                                                           \
+    if (gath)                                                                                           \
+      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, true>), grid, dim3(512), 0,  \
+                         s, in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);     \
+    else if (radd)                                                                                      \
       hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, true>), grid, dim3(512), 0, s, in,  \
                          Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);            \
     else                                                                                                \

@@ -30,9 +30,9 @@ inline int check_launch() {
 inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // fused_layer_ws.hip: wave-specialised layer kernel; false = no instantiation for this tile variant
-bool launch_fused_layer_ws(int variant, bool radd, const pdr_layer_in_t& in, int Cin, const float* Wt,
-                           int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
-                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s);
+bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,
+                           const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
+                           float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s);
 
 // ---- DPP wave reductions (wave64, gfx9 row_shr / row_bcast) -------------------
 // After wave_max_*: lane 63 holds the maximum; callers broadcast with readlane.

@@ -50,7 +50,7 @@ FUSE_SCORE_POOL = False
 # Measured on MI355X (B=32): 17.3 ms/step virtual vs 14.0 ms/step materialised -- the two dependent
 # 64-B gathers per row cost more than the HBM round trip they save -- so it is OFF; kept (and tested)
 # as the starting point for an index-prefetching variant.
-USE_VIRTUAL_FIRST = False
+USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "0") == "1"
 
 
 def _stream():
@@ -70,6 +70,7 @@ def _fill_seg(cseg, seg):
         cseg.gV = _ptr(g["V"][0], g["V"][1])
         cseg.gV0 = _ptr(g["V0"][0], g["V0"][1]) if g.get("V0") is not None else None
         cseg.g_ldv, cseg.g_nsrc = g["ldv"], g["nsrc"]
+        cseg.g_zrow = g.get("zrow", -1)
 
 
 class Act:
@@ -111,11 +112,16 @@ class Act:
 
 
 class FirstOut:
-    """Output of a block's first conv: a materialised (P, ld) tensor, or VIRTUAL = per-source-point table
-    U, per-query tables V / V0 and the neighbour index, read by consumers as a gathered source."""
+    """Output of a block's first conv: a materialised (P, ld) tensor, or VIRTUAL = per-source-point table U
+    (with one all-zero row appended), per-query table V2 = [V | V0] and the neighbour index, read by consumers
+    as a gathered source.  In virtual form the residual columns [res_col0, res_col0 + res.shape... ) may still be
+    materialised (`Yres`): they are consumed as a row-wise residual, which stays a plain read."""
 
-    def __init__(self, Y=None, U=None, V=None, V0=None, idx=None, counts=None, K=0, nsrc=0):
-        self.Y, self.U, self.V, self.V0, self.idx, self.counts, self.K, self.nsrc = Y, U, V, V0, idx, counts, K, nsrc
+    def __init__(self, Y=None, U=None, V2=None, ld=0, has_v0=False, idx=None, counts=None, K=0, nsrc=0, zrow=-1,
+                 Yres=None, res_col0=0, res_cols=0):
+        self.Y, self.U, self.V2, self.ld, self.has_v0 = Y, U, V2, ld, has_v0
+        self.idx, self.counts, self.K, self.nsrc, self.zrow = idx, counts, K, nsrc, zrow
+        self.Yres, self.res_col0, self.res_cols = Yres, res_col0, res_cols
 
     @property
     def virtual(self):
@@ -124,8 +130,10 @@ class FirstOut:
     def seg(self, col0, C):
         if not self.virtual:
             return (self.Y, col0, C, self.Y.shape[1], 1)
-        g = {"V": (self.V, col0), "V0": (self.V0, col0) if self.V0 is not None else None,
-             "ldv": self.V.shape[1], "nsrc": self.nsrc}
+        if self.Yres is not None and col0 >= self.res_col0 and col0 + C <= self.res_col0 + self.res_cols:
+            return (self.Yres, col0 - self.res_col0, C, self.Yres.shape[1], 1)
+        g = {"V": (self.V2, col0), "V0": (self.V2, self.ld + col0) if self.has_v0 else None,
+             "ldv": self.V2.shape[1], "nsrc": self.nsrc, "zrow": self.zrow}
         return (self.U, col0, C, self.U.shape[1], 1, g)
 
     def attach(self, act):
@@ -180,15 +188,24 @@ class Conv:
         self.widths = [w.shape[0] for w in ws]
 
 
-def run_layer(act, conv, stats=False, relu_col0=None):
-    """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch)."""
+def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
+    """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch).
+    extra_rows: zero rows appended to Y (the zero row of a gathered table); out = (tensor, col0): write into
+    columns [col0, col0 + ldy') of an existing (P, ld) tensor instead of allocating."""
     lib = _lib.load()
     assert act.C == conv.Cin, (act.C, conv.Cin)
     # rows of wide, odd-width outputs (105, 140, 297 ... = [first | res | key] GEMMs) start on
     # 128-byte boundaries: pad the leading dimension, consumers address columns through `ld`
     # (narrow outputs: a multiple of 4 floats, so that consumers can stage them with 16-B loads)
     ldy = _pad4(conv.Cout) if (conv.Cout <= 64 or conv.Cout % 32 == 0) else (conv.Cout + 31) // 32 * 32
-    Y = torch.empty((act.P, ldy), dtype=torch.float32, device=conv.Wt.device)
+    if out is not None:
+        Y, ycol0 = out
+        y_ptr, ldy = _ptr(Y, ycol0), Y.shape[1]
+    else:
+        Y = torch.empty((act.P + extra_rows, ldy), dtype=torch.float32, device=conv.Wt.device)
+        if extra_rows:
+            Y[act.P:].zero_()
+        y_ptr = Y.data_ptr()
     tm = lib.pdr_fused_layer_tile_rows(act.rpb, conv.Cout)
     tpb = (act.rpb + tm - 1) // tm
     partial = None
@@ -196,7 +213,7 @@ def run_layer(act, conv, stats=False, relu_col0=None):
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
     _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
-                                   conv.bias.data_ptr(), conv.Cout, Y.data_ptr(), ldy,
+                                   conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
                                    partial.data_ptr() if stats else None,
                                    conv.Cout if relu_col0 is None else relu_col0, _stream()), "fused_layer")
     return Y, partial, tpb
@@ -436,6 +453,10 @@ class _RawConv:
         self.Cin, self.ldw, self.Cout = Wt.shape[0], Wt.shape[1], Cout
 
 
+import os as _os
+_LAB_SKIP_Y1 = _os.environ.get("PDR_LAB_SKIP_Y1") == "1"   # timing experiment only (wrong results)
+
+
 class SplitFirstConv:
     """First 1x1 conv of a grouped block evaluated WITHOUT the grouped (P x Cin) tensor.
 
@@ -475,36 +496,52 @@ class SplitFirstConv:
             self.V0 = None
 
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
-                 virtual=False):
+                 virtual=False, res=None):
         """-> (Y1, partial, tiles_per_batch).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
         consumers read as a gathered source (only the GroupNorm moments are computed here)."""
         lib = _lib.load()
         B, n, Cs = src_feats_cl.shape
         m = query_xyz.shape[1]
         u_in = Act([(xyz4(src_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
-        U, _, _ = run_layer(u_in, self.U)
-        q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
-        V, _, _ = run_layer(q_in, self.V)
-        V0 = None
-        if counts is not None:
-            V0, _, _ = run_layer(q_in, self.V0)
-        assert U.shape[1] == V.shape[1]
+        U, _, _ = run_layer(u_in, self.U, extra_rows=1)         # row B*n: the zero row read for empty balls
         ld = U.shape[1]
+        q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
+        has_v0 = counts is not None
+        V2 = torch.empty((B * m, 2 * ld if has_v0 else ld), dtype=torch.float32, device=U.device)   # [V | V0]
+        run_layer(q_in, self.V, out=(V2, 0))
+        if has_v0:
+            run_layer(q_in, self.V0, out=(V2, ld))
+        ldv = V2.shape[1]
         rpb = m * K
         tpb = (rpb + 127) // 128
         virtual = virtual and s1 is None and s2 is None and (K & (K - 1)) == 0 and 128 % K == 0
         Y = None if virtual else torch.empty((B * rpb, ld), dtype=torch.float32, device=U.device)
         partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
-        _lib.check(lib.pdr_gather_add(
-            U.data_ptr(), ld, n, V.data_ptr(), V0.data_ptr() if V0 is not None else None, ld, idx32.data_ptr(),
-            counts.data_ptr() if counts is not None else None,
-            s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
-            s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
-            B, rpb, K, self.Cout, Y.data_ptr() if Y is not None else None, ld, partial.data_ptr(), relu_col0,
-            _stream()), "gather_add")
-        if virtual:
-            return FirstOut(U=U, V=V, V0=V0, idx=idx32, counts=counts, K=K, nsrc=n), partial, tpb
-        return Y, partial, tpb
+        cptr = counts.data_ptr() if has_v0 else None
+
+        def gather_add(col0, ncols, y, ldy, part, rc0):
+            _lib.check(lib.pdr_gather_add(
+                _ptr(U, col0), ld, n, _ptr(V2, col0), _ptr(V2, ld + col0) if has_v0 else None, ldv,
+                idx32.data_ptr(), cptr,
+                s1.data_ptr() if s1 is not None else None, _ptr(self.r1, col0) if s1 is not None else None,
+                s2.data_ptr() if s2 is not None else None, _ptr(self.r2, col0) if s2 is not None else None,
+                B, rpb, K, ncols, y, ldy, part, rc0, _stream()), "gather_add")
+
+        if not virtual:
+            gather_add(0, self.Cout, None if _LAB_SKIP_Y1 else Y.data_ptr(), ld, partial.data_ptr(), relu_col0)
+            return Y, partial, tpb
+        # virtual: GroupNorm moments only; the residual columns (a row-wise add in their consumer) are the
+        # only part of the first conv's output that is written
+        gather_add(0, self.Cout, None, ld, partial.data_ptr(), relu_col0)
+        Yres = None
+        if res is not None:
+            rc0, rcols = res
+            Yres = torch.empty((B * rpb, _pad4(rcols)), dtype=torch.float32, device=U.device)
+            gather_add(rc0, rcols, Yres.data_ptr(), Yres.shape[1], None, rcols)
+        first = FirstOut(U=U, V2=V2, ld=ld, has_v0=has_v0, idx=idx32, counts=counts if has_v0 else None, K=K,
+                         nsrc=n, zrow=B * n, Yres=Yres, res_col0=res[0] if res else 0,
+                         res_cols=res[1] if res else 0)
+        return first, partial, tpb
 
 
 def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with_centre):
@@ -552,7 +589,9 @@ class FusedGroupedBlock:
                 self.split = SplitFirstConv(self.mlp.first, src_feats_cl.shape[2], 'ball', self.with_abs,
                                             self.with_centre)
             Y1, part1, tpb1 = self.split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
-                                         self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST)
+                                         self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
+                                         res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None
+                                         else None)
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
         else:
             G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
