@@ -267,12 +267,15 @@ int pdr_attention_pool(const float *scores, int lds, const float *values, int ld
  * rows): Y[p,:] = U[b, idx[p], :] + V[p / K, :] (+ s1[p] r1[:] + s2[p] r2[:]); where counts[p / K] <= 0
  * (empty ball, subset=False) Y[p,:] = V0[p / K, :].  Replaces QueryAndGroup / group_knn + the first
  * Conv2d (pointnet2_utils.py:368-414, 497-510; pointnet2_modules.py:119-121).  Moments as in
- * pdr_fused_layer with 128-row tiles.  All leading dimensions multiples of 4 floats.  Y may be NULL
- * (moments only): consumers then read the result as a GATHERED source of pdr_fused_layer. */
+ * pdr_fused_layer with 128-row tiles.  All leading dimensions multiples of 4 floats, all row pointers
+ * 16-byte aligned.  Only the column window [ycol0, ycol0 + ycols) of the result is written, to columns
+ * [0, ycols) of Y (ycol0 a multiple of 4; ycols = -1: through the last column); Y may be NULL (moments
+ * only).  Consumers read the unwritten columns as a GATHERED source of pdr_fused_layer. */
 int pdr_gather_add(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,
                    const int *idx, const int *counts, const float *s1, const float *r1,
                    const float *s2, const float *r2, int B, int rows_per_batch, int K, int Cout,
-                   float *Y, int ldy, float *partial, int relu_col0, pdr_stream_t stream);
+                   float *Y, int ldy, float *partial, int relu_col0, int ycol0, int ycols,
+                   pdr_stream_t stream);
 /* out (B,m,C) = src (B,n,C)[idx (B,m)] */
 int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m, float *out,
                     pdr_stream_t stream);

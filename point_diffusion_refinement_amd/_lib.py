@@ -52,7 +52,7 @@ SIGNATURES = {
     "pdr_knn_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_attention_pool": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
-    "pdr_gather_add": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "pdr_gather_add": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
 }
 
 

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
     const float* __restrict__ s1, const float* __restrict__ r1, const float* __restrict__ s2,
     const float* __restrict__ r2, int rows_per_batch, int K, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0) {
+    float* __restrict__ partial, int relu_col0, int ycol0, int ycol1) {
   constexpr int TM = 128;
   constexpr int RPI = 64 / LPR;            // rows per wave instruction
   constexpr int CW = 4 * LPR;              // columns covered per pass
@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
             y.x = __builtin_fmaf(t2[k], q2.x, y.x); y.y = __builtin_fmaf(t2[k], q2.y, y.y);
             y.z = __builtin_fmaf(t2[k], q2.z, y.z); y.w = __builtin_fmaf(t2[k], q2.w, y.w);
           }
-          if (Y) *reinterpret_cast<float4*>(Y + (row0 + wr0 + rr[k]) * ldy + c) = y;
+          if (Y && c >= ycol0 && c < ycol1)
+            *reinterpret_cast<float4*>(Y + (row0 + wr0 + rr[k]) * ldy + (c - ycol0)) = y;
           const float e[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -371,14 +372,18 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
                               int ldv, const int* idx, const int* counts, const float* s1,
                               const float* r1, const float* s2, const float* r2, int B,
                               int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
-                              int relu_col0, pdr_stream_t stream) {
+                              int relu_col0, int ycol0, int ycols, pdr_stream_t stream) {
   if (!U || !V || !idx || (!Y && !partial) || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 ||
       n_src <= 0)
     return PDR_EINVAL;
   if (B == 0) return PDR_OK;
   if (rows_per_batch % K != 0 || (counts && !V0) || (s1 && !r1) || (s2 && !r2)) return PDR_EINVAL;
   const int c4 = (Cout + 3) & ~3;
-  if (ldu % 4 || ldv % 4 || ldu < c4 || ldv < c4 || (Y && (ldy % 4 || ldy < c4))) return PDR_EINVAL;
+  if (ycols < 0) ycols = Cout - ycol0;                     // -1: every column from ycol0 on
+  // the written window [ycol0, ycol0 + ycols) starts on a float4 boundary; Y holds it from column 0
+  if (Y && (ycol0 < 0 || ycol0 % 4 || ycols <= 0 || ycol0 + ycols > Cout)) return PDR_EINVAL;
+  const int y4 = (ycols + 3) & ~3;
+  if (ldu % 4 || ldv % 4 || ldu < c4 || ldv < c4 || (Y && (ldy % 4 || ldy < y4))) return PDR_EINVAL;
   // rows are moved as float4: every base pointer (possibly offset to a column sub-range) 16-B aligned
   auto al = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
   if (!al(U) || !al(V) || (V0 && !al(V0)) || (Y && !al(Y)) || (r1 && !al(r1)) || (r2 && !al(r2)))
@@ -388,7 +393,8 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
   hipStream_t st = pdr::as_stream(stream);
 #define PDR_GA(LPR)                                                                                   \
   hipLaunchKernelGGL(gather_add_kernel<LPR>, grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
-                     counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0)
+                     counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0, ycol0, \
+                     ycol0 + y4)
   if (Cout <= 64) PDR_GA(16);
   else if (Cout <= 128) PDR_GA(32);
   else PDR_GA(64);

@@ -44,13 +44,12 @@ SPLIT_QUERY_CONV = True
 # Measured: 14.0 ms/step fused vs 13.5 ms/step separate -- the MFMA accumulator layout forces 4-byte
 # value loads in the epilogue, which costs more than the score round trip saves.  OFF; kept and tested.
 FUSE_SCORE_POOL = False
-# Optionally that first conv's (P x Cout) output is never written: its three consumers (second MLP
-# conv, attention key, residual) gather U[idx] + V through the A-loader of pdr_fused_layer (ball-query
-# blocks only; the kNN form carries two extra per-position terms and is always materialised).
-# Measured on MI355X (B=32): 17.3 ms/step virtual vs 14.0 ms/step materialised -- the two dependent
-# 64-B gathers per row cost more than the HBM round trip they save -- so it is OFF; kept (and tested)
-# as the starting point for an index-prefetching variant.
-USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "0") == "1"
+# The first conv's (P x Cout) output is not written (ball-query blocks): its consumers (second MLP conv,
+# attention key) gather U[idx] + V in the producer waves of the wave-specialised layer kernel; only the
+# residual columns (a row-wise add in their consumer) are materialised, in the same pass that computes the
+# GroupNorm moments.  Measured on MI355X (B=32, same box): 12.28 ms/step vs 12.58 materialised.  The kNN form
+# carries two extra per-position terms and is always materialised.  PDR_VIRTUAL_FIRST=0 turns it off.
+USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1"
 
 
 def _stream():
@@ -519,25 +518,25 @@ class SplitFirstConv:
         partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
         cptr = counts.data_ptr() if has_v0 else None
 
-        def gather_add(col0, ncols, y, ldy, part, rc0):
+        def gather_add(y, ldy, ycol0, ycols):
             _lib.check(lib.pdr_gather_add(
-                _ptr(U, col0), ld, n, _ptr(V2, col0), _ptr(V2, ld + col0) if has_v0 else None, ldv,
-                idx32.data_ptr(), cptr,
-                s1.data_ptr() if s1 is not None else None, _ptr(self.r1, col0) if s1 is not None else None,
-                s2.data_ptr() if s2 is not None else None, _ptr(self.r2, col0) if s2 is not None else None,
-                B, rpb, K, ncols, y, ldy, part, rc0, _stream()), "gather_add")
+                U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
+                s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
+                s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
+                B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, _stream()), "gather_add")
 
         if not virtual:
-            gather_add(0, self.Cout, None if _LAB_SKIP_Y1 else Y.data_ptr(), ld, partial.data_ptr(), relu_col0)
+            gather_add(None if _LAB_SKIP_Y1 else Y.data_ptr(), ld, 0, -1)
             return Y, partial, tpb
-        # virtual: GroupNorm moments only; the residual columns (a row-wise add in their consumer) are the
-        # only part of the first conv's output that is written
-        gather_add(0, self.Cout, None, ld, partial.data_ptr(), relu_col0)
+        # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
+        # consumer, which stays a plain read) are written -- one pass
         Yres = None
-        if res is not None:
-            rc0, rcols = res
-            Yres = torch.empty((B * rpb, _pad4(rcols)), dtype=torch.float32, device=U.device)
-            gather_add(rc0, rcols, Yres.data_ptr(), Yres.shape[1], None, rcols)
+        if res is not None and res[0] % 4 == 0:
+            Yres = torch.empty((B * rpb, _pad4(res[1])), dtype=torch.float32, device=U.device)
+            gather_add(Yres.data_ptr(), Yres.shape[1], res[0], res[1])
+        else:
+            res = None
+            gather_add(None, ld, 0, -1)
         first = FirstOut(U=U, V2=V2, ld=ld, has_v0=has_v0, idx=idx32, counts=counts if has_v0 else None, K=K,
                          nsrc=n, zrow=B * n, Yres=Yres, res_col0=res[0] if res else 0,
                          res_cols=res[1] if res else 0)

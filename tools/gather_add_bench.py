@@ -8,7 +8,7 @@ import torch
 from point_diffusion_refinement_amd import _lib
 
 
-def run(B, n_src, m, K, Cout, knn=False, reps=20):
+def run(B, n_src, m, K, Cout, knn=False, reps=20, write=True, stats=True):
     lib = _lib.load()
     dev = torch.device("cuda:0")
     ld = (Cout + 3) // 4 * 4
@@ -29,7 +29,8 @@ def run(B, n_src, m, K, Cout, knn=False, reps=20):
 
     def call():
         _lib.check(lib.pdr_gather_add(p(U), ld, n_src, p(V), p(V0), ld, p(idx), p(counts), p(s1), p(r1), None, None,
-                                      B, m * K, K, Cout, p(Y), ld, p(partial), 0, st), "gather_add")
+                                      B, m * K, K, Cout, p(Y) if write else None, ld, p(partial) if stats else None,
+                                      0, 0, -1, st), "gather_add")
     for _ in range(3):
         call()
     torch.cuda.synchronize()
@@ -41,11 +42,15 @@ def run(B, n_src, m, K, Cout, knn=False, reps=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     gb = 2 * B * m * K * Cout * 4 / 1e9
-    print("B=%d n_src=%d m=%d K=%d Cout=%d knn=%d: %.1f us  %.0f GB/s" % (B, n_src, m, K, Cout, knn, us, gb / us * 1e6))
+    print("B=%d n_src=%d m=%d K=%d Cout=%d knn=%d write=%d stats=%d: %.1f us  %.0f GB/s" %
+          (B, n_src, m, K, Cout, knn, write, stats, us, gb / us * 1e6))
 
 
 if __name__ == "__main__":
     run(32, 2048, 2048, 32, 96)
+    run(32, 2048, 2048, 32, 96, write=False)
+    run(32, 2048, 2048, 32, 96, stats=False)
+    run(32, 2048, 2048, 32, 32, stats=False)
     run(32, 2048, 1024, 32, 64)
     run(32, 1024, 256, 32, 128)
     run(32, 256, 64, 32, 256)
