@@ -1,7 +1,7 @@
 """Live roofline of the dominant hand-written kernel of the reverse step (used by bench.py).
 
 The dominant kernel (largest share of the step in profiles/*_kernel_stats.csv) is
-`fused_layer_ws_kernel<2,2,2,2,32,false>`: the wave-specialised 128 x 128-tile fp32-MFMA layer kernel
+`fused_layer_ws_kernel<2,2,2,2,32,false,false>`: the wave-specialised 128 x 128-tile fp32-MFMA layer kernel
 (csrc/fused_layer_ws.hip) that evaluates the wide 1x1-conv GEMMs of the SA / feature-transfer /
 kNN-FP blocks.  Its roof is the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
 
@@ -21,7 +21,7 @@ from point_diffusion_refinement_amd import _lib
 from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
 
 DOMINANT_VARIANT = 4          # pdr_fused_layer_variant(): 128 x 128 tile, 2-D grid
-DOMINANT_SYMBOL = "fused_layer_ws_kernel<2, 2, 2, 2, 32, false>"
+DOMINANT_SYMBOL = "fused_layer_ws_kernel<2, 2, 2, 2, 32, false, false>"
 FP32_MFMA_PEAK_TFLOPS = 157.3
 
 
@@ -46,13 +46,15 @@ def dominant_kernel_roofline(sampler, reps=3):
     records = []
     original = FN.run_layer
 
-    def timed(act, conv, stats=False, relu_col0=None):
-        hit = lib.pdr_fused_layer_variant(act.rpb, conv.Cout) == DOMINANT_VARIANT and act.radd is None
+    def timed(act, conv, *a, **k):
+        # the plain (no residual, no gathered source) 128 x 128 instantiation
+        hit = (lib.pdr_fused_layer_variant(act.rpb, conv.Cout) == DOMINANT_VARIANT and act.radd is None
+               and act.gidx is None)
         if not hit:
-            return original(act, conv, stats, relu_col0)
+            return original(act, conv, *a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = original(act, conv, stats, relu_col0)
+        out = original(act, conv, *a, **k)
         e1.record()
         seg_bytes = sum(4 * sg[2] * act.P // sg[4] for sg in act.segs)
         records.append((e0, e1, 2.0 * act.P * conv.Cin * conv.Cout, seg_bytes + 4.0 * act.P * conv.Cout))
