@@ -452,10 +452,6 @@ class _RawConv:
         self.Cin, self.ldw, self.Cout = Wt.shape[0], Wt.shape[1], Cout
 
 
-import os as _os
-_LAB_SKIP_Y1 = _os.environ.get("PDR_LAB_SKIP_Y1") == "1"   # timing experiment only (wrong results)
-
-
 class SplitFirstConv:
     """First 1x1 conv of a grouped block evaluated WITHOUT the grouped (P x Cin) tensor.
 
@@ -526,7 +522,7 @@ class SplitFirstConv:
                 B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, _stream()), "gather_add")
 
         if not virtual:
-            gather_add(None if _LAB_SKIP_Y1 else Y.data_ptr(), ld, 0, -1)
+            gather_add(Y.data_ptr(), ld, 0, -1)
             return Y, partial, tpb
         # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
         # consumer, which stays a plain read) are written -- one pass
