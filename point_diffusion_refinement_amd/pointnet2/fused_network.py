@@ -490,15 +490,24 @@ class SplitFirstConv:
             self.V = _RawConv(W_x - W_rel, bias, Cout)
             self.V0 = None
 
+    def source_table(self, src_feats_cl, src_xyz):
+        """U (B*n + 1, ld): the per-source-point half of the conv; its last row is all zero (read for empty
+        balls).  Depends on the SOURCE cloud only, so callers whose source is static across reverse steps (the
+        feature-transfer blocks read the retained condition features) compute it once per batch."""
+        B, n, Cs = src_feats_cl.shape
+        u_in = Act([(xyz4(src_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
+        U, _, _ = run_layer(u_in, self.U, extra_rows=1)
+        return U
+
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
-                 virtual=False, res=None):
+                 virtual=False, res=None, U=None):
         """-> (Y1, partial, tiles_per_batch).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
         consumers read as a gathered source (only the GroupNorm moments are computed here)."""
         lib = _lib.load()
         B, n, Cs = src_feats_cl.shape
         m = query_xyz.shape[1]
-        u_in = Act([(xyz4(src_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
-        U, _, _ = run_layer(u_in, self.U, extra_rows=1)         # row B*n: the zero row read for empty balls
+        if U is None:
+            U = self.source_table(src_feats_cl, src_xyz)
         ld = U.shape[1]
         q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
         has_v0 = counts is not None
@@ -571,6 +580,23 @@ class FusedGroupedBlock:
         self.att = FusedAttention(att)
         self.mlp = FusedMlp(mlp, bank, extra_convs=[self.att.key_conv])
         self.split = None   # built lazily (needs the source feature width)
+        self.static_U = None
+
+    def _make_split(self, Cs):
+        if self.split is None:
+            self.split = SplitFirstConv(self.mlp.first, Cs, 'ball', self.with_abs, self.with_centre)
+        return self.split
+
+    def prepare_static_source(self, src_xyz, src_feats_cl):
+        """The source cloud of this block does not change between reverse steps (retained condition features):
+        evaluate its per-source table once per batch, in place when a captured graph already reads the buffer."""
+        if not USE_SPLIT_FIRST:
+            return
+        U = self._make_split(src_feats_cl.shape[2]).source_table(src_feats_cl, src_xyz)
+        if self.static_U is not None and self.static_U.shape == U.shape:
+            self.static_U.copy_(U)
+        else:
+            self.static_U = U
 
     def neighbours(self, src_xyz, new_xyz):
         return _ext.ball_query(new_xyz, src_xyz, self.radius, self.nsample)
@@ -580,13 +606,11 @@ class FusedGroupedBlock:
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
         K = self.nsample
         if USE_SPLIT_FIRST:
-            if self.split is None:
-                self.split = SplitFirstConv(self.mlp.first, src_feats_cl.shape[2], 'ball', self.with_abs,
-                                            self.with_centre)
-            Y1, part1, tpb1 = self.split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
-                                         self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
-                                         res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None
-                                         else None)
+            split = self._make_split(src_feats_cl.shape[2])
+            Y1, part1, tpb1 = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
+                                    self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
+                                    res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
+                                    U=self.static_U)
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
         else:
             G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
@@ -689,6 +713,15 @@ class FusedCloudConditionNet:
 
         self.enc_cl = convert(self.enc_cl, net.encoder_cond_features)
         self.dec_cl = convert(self.dec_cl, net.decoder_cond_features)
+        # the feature-transfer blocks read these static clouds as their SOURCE: the per-source half of their
+        # first conv (SplitFirstConv.source_table) is evaluated here, once per batch, not once per step
+        with torch.no_grad():
+            _XYZ4.clear()
+            for i, blk in enumerate(self.enc_map):
+                blk.prepare_static_source(net.l_uvw[i], self.enc_cl[i])
+            for i, blk in enumerate(self.dec_map):
+                blk.prepare_static_source(net.l_uvw[i], self.dec_cl[i])
+            _XYZ4.clear()
         self._synced = True
 
     @torch.no_grad()
