@@ -226,3 +226,108 @@ def test_graphed_fast_sampler_matches_fastdpm_reference_loop(cuda, method, sched
         got = sampler.sample((2, 256, 3), cond, label)
         rel = ((got - want).abs() / (want.abs() + 1.0))
         assert rel.max() < 1e-3 and (rel < 1e-4).float().mean() > 0.99, (use_graph, rel.max())
+
+
+def _random_layer_case(seed, cuda):
+    """One random pdr_fused_layer problem + its float64 reference (aligned segments => the wave-specialised
+    kernel; `gath` adds a gathered first-conv source with empty balls)."""
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    rpb = int(rng.choice([16, 32, 96, 128, 160, 256, 384, 1000, 2048]))
+    B = int(rng.integers(1, 4))
+    K = int(rng.choice([8, 16, 32]))
+    if rpb % K:
+        rpb = (rpb // K + 1) * K
+    P = B * rpb
+    gath = bool(rng.integers(0, 2)) and 128 % K == 0
+    nseg = int(rng.integers(1, 4))
+    widths = [int(rng.choice([3, 4, 17, 32, 41, 64, 100, 128, 200])) for _ in range(nseg)]
+    Cin = sum(widths)
+    Cout = int(rng.choice([3, 32, 35, 64, 96, 105, 128, 140, 200, 256, 427]))
+    segs, cols = [], []
+    idx = cnt = None
+    for si, C in enumerate(widths):
+        ld = (C + 3) // 4 * 4 + 4 * int(rng.integers(0, 2))
+        if gath and si == 0:
+            n_src = int(rng.integers(K, 3 * K))
+            U = torch.randn(B * n_src + 1, ld, generator=g)
+            U[-1] = 0
+            V2 = torch.randn(P // K, 2 * ld, generator=g)
+            idx = torch.randint(0, n_src, (P,), generator=g, dtype=torch.int32)
+            cnt = torch.randint(0, 3, (P // K,), generator=g, dtype=torch.int32)       # 1/3 empty balls
+            bsel = torch.arange(P) // rpb
+            rows = U[bsel * n_src + idx.long()][:, :C] + V2[torch.arange(P) // K][:, :C]
+            empty = (cnt[torch.arange(P) // K] <= 0).unsqueeze(1)
+            cols.append(torch.where(empty, V2[torch.arange(P) // K][:, ld:ld + C], rows))
+            U, V2 = U.to(cuda), V2.to(cuda)
+            segs.append((U, 0, C, ld, 1, {"V": (V2, 0), "V0": (V2, ld), "ldv": 2 * ld, "nsrc": n_src,
+                                            "zrow": B * n_src}))
+        else:
+            div = K if (rng.integers(0, 3) == 0 and not gath) else 1
+            t = torch.randn(P // div, ld, generator=g)
+            cols.append(t[:, :C].repeat_interleave(div, 0))
+            segs.append((t.to(cuda), 0, C, ld, div))
+    x = torch.cat(cols, 1).double()
+    has_ss, has_add = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    has_radd = bool(rng.integers(0, 2)) and nseg == 1 and not gath
+    has_oadd = bool(rng.integers(0, 2))
+    pre, post = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    scale = torch.randn(B, Cin, generator=g) if has_ss else None
+    shift = torch.randn(B, Cin, generator=g) if has_ss else None
+    add = torch.randn(B, Cin, generator=g) if has_add else None
+    bidx = torch.arange(P) // rpb
+    if pre:
+        x = x.relu()
+    if has_ss:
+        x = x * scale[bidx].double() + shift[bidx].double()
+    if post:
+        x = x.relu()
+    if has_add:
+        x = x + add[bidx].double()
+    radd = None
+    if has_radd:
+        rt = torch.randn(P, (Cin + 3) // 4 * 4, generator=g)
+        x = x + rt[:, :Cin].double()
+        radd = (rt.to(cuda), 0, Cin, rt.shape[1], 1)
+    W = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = x @ W.t().double() + bias.double()
+    act = FN.Act(segs, P, B, rpb, scale=None if scale is None else scale.to(cuda),
+                 shift=None if shift is None else shift.to(cuda), add=None if add is None else add.to(cuda),
+                 add_ld=Cin, radd=radd, pre_relu=pre, post_relu=post)
+    if gath:
+        act.gidx, act.gcnt, act.gK = idx.to(cuda), cnt.to(cuda), K
+    if has_oadd:
+        od = torch.randn(P // K, (Cout + 3) // 4 * 4, generator=g)
+        ref = ref + od[:, :Cout].repeat_interleave(K, 0).double()
+        act.oadd = (od.to(cuda), K)
+    return act, _conv(W.to(cuda), bias.to(cuda)), ref, (B, rpb, Cout)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("ws", ["1", "0"])
+def test_fused_layer_random_sweep(cuda, ws, monkeypatch):
+    """40 random layer problems through both kernel families (PDR_FUSED_WS is read once per process, so the
+    uniform-wave family is exercised in a child process)."""
+    if ws == "0":
+        import subprocess, sys, os
+        env = dict(os.environ, PDR_FUSED_WS="0", PDR_SWEEP_CHILD="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                            "random_sweep and 1"], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    relu_cols = [0, 17, 10 ** 6]
+    for seed in range(40):
+        act, conv, ref, (B, rpb, Cout) = _random_layer_case(seed, cuda)
+        rc0 = relu_cols[seed % 3]
+        Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=min(rc0, Cout))
+        torch.cuda.synchronize()
+        got = Y[:, :Cout].double().cpu()
+        assert torch.isfinite(got).all(), seed
+        assert _rel(got, ref) < 5e-5, (seed, _rel(got, ref))
+        f = ref.clone()
+        f[:, min(rc0, Cout):] = f[:, min(rc0, Cout):].relu()
+        s1 = f.view(B, rpb, Cout).sum(1)
+        s2 = (f * f).view(B, rpb, Cout).sum(1)
+        st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
+        assert _rel(st[..., 0], s1) < 2e-4 and _rel(st[..., 1], s2) < 2e-4, seed
