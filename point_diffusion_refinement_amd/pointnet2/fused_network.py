@@ -43,7 +43,7 @@ SPLIT_QUERY_CONV = True
 # Last attention score conv + mask + softmax + weighted sum in one kernel (scores never written).
 # Measured: 14.0 ms/step fused vs 13.5 ms/step separate -- the MFMA accumulator layout forces 4-byte
 # value loads in the epilogue, which costs more than the score round trip saves.  OFF; kept and tested.
-FUSE_SCORE_POOL = False
+FUSE_SCORE_POOL = __import__("os").environ.get("PDR_FUSE_SCORE_POOL", "0") == "1"
 # The first conv's (P x Cout) output is not written (ball-query blocks): its consumers (second MLP conv,
 # attention key) gather U[idx] + V in the producer waves of the wave-specialised layer kernel; only the
 # residual columns (a row-wise add in their consumer) are materialised, in the same pass that computes the
