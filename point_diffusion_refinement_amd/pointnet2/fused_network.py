@@ -49,6 +49,9 @@ FUSE_SCORE_POOL = __import__("os").environ.get("PDR_FUSE_SCORE_POOL", "0") == "1
 # residual columns (a row-wise add in their consumer) are materialised, in the same pass that computes the
 # GroupNorm moments.  Measured on MI355X (B=32, same box): 12.28 ms/step vs 12.58 materialised.  The kNN form
 # carries two extra per-position terms and is always materialised.  PDR_VIRTUAL_FIRST=0 turns it off.
+# First call of a batch: run the condition branch through the fused blocks too (False: layer-by-layer torch path,
+# what rounds of this code did before; kept for A/B and as the cross-check of the tests).
+FUSE_CONDITION_BRANCH = __import__("os").environ.get("PDR_FUSE_CONDITION_BRANCH", "1") == "1"
 USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1"
 
 
@@ -683,6 +686,15 @@ class FusedCloudConditionNet:
             blk.npoint = sa.npoint
             self.sa.append(blk)
         self.fp = [FusedKnnFP(fp, b) for fp in net.FP_modules]
+        # condition branch (evaluated once per batch): same block types, no embeddings (include_t / condition False)
+        self.cond_sa = []
+        for sa in net.SA_modules_condition:
+            if len(sa.groupers) != 1 or not sa.use_attention_module:
+                raise NotImplementedError("fused path: single-scale SA with attention")
+            blk = FusedGroupedBlock(sa.groupers[0], sa.mlps[0], sa.attention_modules[0], b)
+            blk.npoint = sa.npoint
+            self.cond_sa.append(blk)
+        self.cond_fp = [FusedKnnFP(fp, b) for fp in net.FP_modules_condition]
         head = list(net.fc_lyaer)
         if not (len(head) == 4 and isinstance(head[1], nn.GroupNorm) and isinstance(head[2], nn.ReLU)):
             raise NotImplementedError("fused path: Conv1d -> GroupNorm -> ReLU -> Conv1d head")
@@ -724,14 +736,50 @@ class FusedCloudConditionNet:
             _XYZ4.clear()
         self._synced = True
 
+    def _condition_branch(self, condition):
+        """Condition branch of a new batch (pointnet2_with_pcld_condition.py:360-369, 383-414 of the reference:
+        global PointNet, SA_modules_condition, FP_modules_condition) through the fused blocks; fills the
+        network's retained features in the REFERENCE layout, exactly what the layer-by-layer path retains."""
+        net, bank = self.net, self.bank
+        uvw = condition[:, :, 0:3].contiguous()
+        cond0 = torch.cat([condition[:, :, 3:], uvw / net.scale_factor], dim=2).contiguous() \
+            if condition.shape[2] > 3 else (uvw / net.scale_factor)
+        raw = net.partial_in_fea_dim - 3 if net.attach_position_to_input_feature else net.partial_in_fea_dim
+        g_in = torch.cat([uvw, condition[:, :, 3:3 + raw]], dim=2) if raw > 0 else uvw
+        net.global_feature = net.global_pnet(g_in.transpose(1, 2)).detach().clone()
+        l_uvw, l_cond = [uvw], [cond0]
+        for i, sa in enumerate(self.cond_sa):
+            sel = _ext.furthest_point_sampling(l_uvw[i], sa.npoint)
+            l_uvw.append(gather_rows(l_uvw[i], sel))
+            centre = gather_rows(l_cond[i], sel)
+            l_cond.append(sa(l_uvw[i], l_cond[i], l_uvw[i + 1], centre, bank, subset=True))
+        net.l_uvw = l_uvw
+        net.encoder_cond_features = [f.transpose(1, 2).contiguous() for f in l_cond]
+        for i in range(-1, -(len(self.cond_fp) + 1), -1):
+            l_cond[i - 1] = self.cond_fp[i](l_uvw[i - 1], l_uvw[i], l_cond[i - 1], l_cond[i], bank)
+        net.decoder_cond_features = [f.transpose(1, 2).contiguous() for f in l_cond]
+        self._synced = False
+
     @torch.no_grad()
     def forward(self, pointcloud, condition, ts=None, label=None, use_retained_condition_feature=True):
         net, hp, bank = self.net, self.net.hparams, self.bank
-        if not use_retained_condition_feature or net.encoder_cond_features is None or \
-                net.decoder_cond_features is None or net.global_feature is None:
-            # first step of a batch (condition branch not retained yet): reference-layout path
-            return net(pointcloud, condition, ts=ts, label=label,
-                       use_retained_condition_feature=use_retained_condition_feature)
+        fresh = not use_retained_condition_feature or net.encoder_cond_features is None or \
+            net.decoder_cond_features is None or net.global_feature is None
+        if fresh:
+            if not FUSE_CONDITION_BRANCH:
+                # first step of a batch (condition branch not retained yet): reference-layout path
+                return net(pointcloud, condition, ts=ts, label=label,
+                           use_retained_condition_feature=use_retained_condition_feature)
+            _XYZ4.clear()
+            self._condition_branch(condition)
+        try:
+            return self._forward_cached(pointcloud, condition, ts, label)
+        finally:
+            if not use_retained_condition_feature:
+                self.reset_cond_features()
+
+    def _forward_cached(self, pointcloud, condition, ts, label):
+        net, hp, bank = self.net, self.net.hparams, self.bank
         B, N, _ = pointcloud.shape
         _XYZ4.clear()
         xyz = pointcloud[:, :, 0:3].contiguous()

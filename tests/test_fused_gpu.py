@@ -331,3 +331,49 @@ def test_fused_layer_random_sweep(cuda, ws, monkeypatch):
         s2 = (f * f).view(B, rpb, Cout).sum(1)
         st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
         assert _rel(st[..., 0], s1) < 2e-4 and _rel(st[..., 1], s2) < 2e-4, seed
+
+
+@pytest.mark.parametrize("cfg_name", ["small", "ddpm"])
+def test_fused_first_call_runs_the_condition_branch(cuda, cfg_name):
+    """First call of a batch (condition branch + global PointNet, pointnet2_with_pcld_condition.py:360-414 of the
+    reference) through the fused blocks == layer-by-layer path: output AND the retained features."""
+    if cfg_name == "small":
+        net, fused = _pair(small_fused_config(), 25, cuda)
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(2, 256, 3, generator=g).to(cuda)
+        cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
+        ts, label = torch.tensor([7.0, 3.0], device=cuda), torch.tensor([2, 9], device=cuda)
+    else:
+        torch.manual_seed(1)
+        net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
+        fused = FN.FusedCloudConditionNet(net)
+        x, cond, label = synthetic_batch(2, seed=5, device=cuda)
+        ts = torch.tensor([999.0, 40.0], device=cuda)
+
+    def close(a, b, what):
+        err = ((a - b).abs() / (b.abs() + 1.0))
+        assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (what, float(err.max()))
+
+    with torch.no_grad():
+        net.reset_cond_features()
+        ref = net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        ref_cache = ([net.global_feature.clone()] + [f.clone() for f in net.encoder_cond_features] +
+                     [f.clone() for f in net.decoder_cond_features])
+        fused.reset_cond_features()
+        assert net.encoder_cond_features is None
+        got = fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        got_cache = [net.global_feature] + list(net.encoder_cond_features) + list(net.decoder_cond_features)
+        close(got, ref, "eps")
+        assert len(got_cache) == len(ref_cache)
+        for i, (a, b) in enumerate(zip(got_cache, ref_cache)):
+            assert a.shape == b.shape
+            close(a, b, "cache %d" % i)
+        # a cached step on top of the fused-filled cache
+        got2 = fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+        ref2 = net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+        close(got2, ref2, "cached eps")
+        # not retained (the refinement stage calls the network this way): same output, nothing kept
+        fused.reset_cond_features()
+        got3 = fused(x, cond, ts=ts, label=label, use_retained_condition_feature=False)
+        close(got3, ref, "unretained eps")
+        assert net.encoder_cond_features is None and net.global_feature is None
