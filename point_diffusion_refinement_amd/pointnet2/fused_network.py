@@ -761,7 +761,9 @@ class FusedCloudConditionNet:
         self._synced = False
 
     @torch.no_grad()
-    def forward(self, pointcloud, condition, ts=None, label=None, use_retained_condition_feature=True):
+    def forward(self, pointcloud, condition, ts=None, label=None, use_retained_condition_feature=False):
+        """Same signature and default as PointNet2CloudCondition.forward (:276): without retention the condition
+        branch is evaluated for this call only (the refinement stage); samplers pass True."""
         net, hp, bank = self.net, self.net.hparams, self.bank
         fresh = not use_retained_condition_feature or net.encoder_cond_features is None or \
             net.decoder_cond_features is None or net.global_feature is None

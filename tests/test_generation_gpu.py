@@ -107,6 +107,7 @@ def test_refine_completion_with_upsampling_matches_the_cpu_oracle_pipeline():
     with torch.no_grad():
         fine_gpu = G.refine_completion(net_gpu, coarse.to(cuda), cond.to(cuda), label.to(cuda), 0.001, 4)
         cd_gpu = calc_cd(fine_gpu, gt.to(cuda))[1]
+
         with oracle_ops():
             fine_cpu = G.refine_completion(net_cpu, coarse, cond, label, 0.001, 4)
             cd_cpu = calc_cd(fine_cpu, gt)[1]
@@ -117,3 +118,25 @@ def test_refine_completion_with_upsampling_matches_the_cpu_oracle_pipeline():
     assert np.abs(d_cpu).max() > 0
     np.testing.assert_allclose(d_gpu, d_cpu, rtol=2e-2, atol=2e-3 * np.abs(d_cpu).max())
     np.testing.assert_allclose(cd_gpu.cpu().numpy(), cd_cpu.numpy(), rtol=1e-4)
+
+
+def test_refine_completion_on_the_fused_network():
+    """The refinement stage with the whole forward (condition branch included, no time embedding) on the fused
+    kernels == the layer-by-layer network over the same HIP ops."""
+    cuda = torch.device("cuda:0")
+
+    def cfg():
+        c = small_fused_config(include_t=False)
+        c["point_upsample_factor"] = 4
+        return c
+    net = fill_deterministic(PointNet2CloudCondition(cfg()), 43).eval().to(cuda)
+    cond, label, gt = (t.to(cuda) for t in _dataset(0, 4))
+    coarse = gt + 0.02 * torch.randn(gt.shape, generator=torch.Generator().manual_seed(4)).to(cuda)
+    with torch.no_grad():
+        want = G.refine_completion(net, coarse, cond, label, 0.001, 4)
+        got = G.refine_completion(FN.FusedCloudConditionNet(net), coarse, cond, label, 0.001, 4)
+    assert got.shape == (4, 4 * N, 3)
+    d_want = want - coarse.repeat_interleave(4, 1)
+    d_got = got - coarse.repeat_interleave(4, 1)
+    err = (d_got - d_want).abs() / (d_want.abs() + d_want.abs().max())
+    assert float(err.max()) < 1e-2 and float((err < 1e-3).float().mean()) > 0.99, float(err.max())

@@ -80,11 +80,11 @@ def main():
         net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
         fused.sync_condition()
         for _ in range(2):
-            fused(x, cond, ts=ts - 1, label=label)
+            fused(x, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
         records.clear()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fused(x, cond, ts=ts - 2, label=label)
+        fused(x, cond, ts=ts - 2, label=label, use_retained_condition_feature=True)
         e1.record()
     torch.cuda.synchronize()
     print("eager fused step: %.2f ms" % e0.elapsed_time(e1))
