@@ -1,5 +1,6 @@
-// fused_layer_ws.hip -- wave-specialised form of the fused layer kernel (fused_layer.hip) for the
-// float4-staged, non-gathered case, i.e. every steady-state layer of the reverse step.
+// fused_layer_ws.hip -- wave-specialised form of the fused layer kernel (fused_layer.hip) for
+// float4-staged sources (plain, neighbour-broadcast, or GATHERED first-conv tables), i.e. every
+// steady-state layer of the reverse step.
 //
 // Why: in fused_layer_kernel every wave both stages the next K-chunk (address arithmetic, prologue
 // math, LDS stores: ~450 issue slots per chunk) and runs the MFMAs of the current one, at 247 VGPRs
@@ -14,6 +15,10 @@
 // the producers.  Workgroups are persistent over row tiles and the chunk sequence runs across tile
 // boundaries, so the first chunk of the next tile is staged during the epilogue of the current one.
 // Register budget 128 (consumers: 64 accumulators, producers: one chunk in flight) = 4 waves / SIMD.
+// Epilogue: accumulators start at the bias, half tiles are transposed through LDS into dwordx4 row
+// stores, the GroupNorm moments of the tile are folded across waves with an LDS ticket (no barrier
+// that the producers would have to join).  The reasons behind each of these choices (VALU
+// instructions wait behind MFMAs, FLAT loads break counted waits, ...) are in DESIGN.md section 4.1.
 //
 // Results equal fused_layer_kernel up to fp32 summation order (the bias is the accumulators' initial value here).
 #include "pdr_common.h"
