@@ -151,9 +151,9 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // GATHERED sources (first conv of a grouped block consumed without materialising it, see
     // pdr_gather_add): x[p] = U[b, idx[p]] + V[p / K]; an empty ball reads the table's zero row + V0.
     // Per tile: this thread's neighbour indices (-1 = empty ball); per (tile, segment): byte offsets.
-    int g_idx[GATH ? APT4 : 1];
+    int g_idx[GATH ? APT4 : 1], n_idx[GATH ? APT4 : 1], n_cnt[GATH ? APT4 : 1];
     unsigned v_off[GATH ? APT4 : 1];
-    int g_tile = -1;
+    int g_tile = -1, n_tile = -1;
     const int gsh = GATH ? __builtin_ctz(in.gK) : 0;
     bool Rgath = false;                                // chunk in flight comes from a gathered segment
     // one chunk in registers (plain arrays: as members of a struct one W quad ended up in scratch)
@@ -176,15 +176,35 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       const bool f_g = GATH && seg.gV != nullptr;               // uniform
       if constexpr (GATH) {
         if (c.tile != g_tile) {                                  // uniform: first chunk of a tile
-          g_tile = c.tile;
           off_sg = -1;
+          if (c.tile == n_tile) {
+            // indices prefetched while the previous tile's last chunk was fetched: the dependent
+            // index -> row load chain is off the per-tile critical path
+#pragma unroll
+            for (int i = 0; i < APT4; ++i) g_idx[i] = n_cnt[i] <= 0 ? -1 : n_idx[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < APT4; ++i) {
+              const long p = row0 + min(vr0 + VSTEP * i, nvalid - 1);
+              const int id = in.gidx[p];
+              const int cnt = in.gcnt ? in.gcnt[p >> gsh] : 1;
+              g_idx[i] = cnt <= 0 ? -1 : id;
+            }
+          }
+          g_tile = c.tile;
+        }
+        const int nt = c.tile + static_cast<int>(gridDim.x);
+        if (last_of_tile(c) && nt < n_row_tiles) {              // uniform: prefetch the next tile's indices
+          const int nb = nt / tpb, ntb = nt - nb * tpb;
+          const long nrow0 = static_cast<long>(nb) * rpb + static_cast<long>(ntb) * TM;
+          const int nnv = min(TM, rpb - ntb * TM);
 #pragma unroll
           for (int i = 0; i < APT4; ++i) {
-            const long p = row0 + min(vr0 + VSTEP * i, nvalid - 1);
-            const int id = in.gidx[p];
-            const int cnt = in.gcnt ? in.gcnt[p >> gsh] : 1;
-            g_idx[i] = cnt <= 0 ? -1 : id;
+            const long p = nrow0 + min(vr0 + VSTEP * i, nnv - 1);
+            n_idx[i] = in.gidx[p];
+            n_cnt[i] = in.gcnt ? in.gcnt[p >> gsh] : 1;
           }
+          n_tile = nt;
         }
       }
       // every load = uniform base (scalar registers) + 32-bit per-thread byte offset
