@@ -299,3 +299,39 @@ def test_state_dict_is_key_for_key_compatible_with_the_ddpm_config():
     got = [[k, "x".join(str(d) for d in v.shape)] for k, v in net.state_dict().items()]
     assert got == want and len(got) == 837
     assert sum(p.numel() for p in net.parameters()) == 9758871
+
+
+@pytest.mark.parametrize("method,schedule,kappa", [("var", "quadratic", 0.5), ("step", "linear", 1.0)])
+def test_graphed_samplers_reproduce_the_eager_loops_on_the_cpu(method, schedule, kappa):
+    """Host logic of reverse_sampler.py without a GPU (eager mode, oracle ops): the table-driven DDPM and FastDPM
+    loops are the same arithmetic, in the same order, as util.sampling / fast_sampling_function_v2 -> bit-equal."""
+    import contextlib, io
+    from tests.golden.det_weights import fill_deterministic
+    from tests.golden.tiny_config import tiny_pointnet_config
+    from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG
+    from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedFastSampler, GraphedReverseSampler
+    net = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 7).eval()
+    g = torch.Generator().manual_seed(2)
+    cond = torch.cat([torch.rand(2, 96, 3, generator=g) * 2 - 1, torch.ones(2, 96, 1)], 2)
+    label = torch.tensor([1, 5])
+    util.set_device(torch.device("cpu"))
+    util.set_noise_source('cpu')
+    try:
+        with oracle_ops(), torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            dh = util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG)
+            torch.manual_seed(3)
+            want = util_fastdpmv2.fast_sampling_function_v2(net, (2, 64, 3), dh, DIFFUSION_CONFIG, length=5,
+                                                            sampling_method=method, schedule=schedule, kappa=kappa,
+                                                            label=label, verbose=False, condition=cond)
+            torch.manual_seed(3)
+            got = GraphedFastSampler(net, dh, DIFFUSION_CONFIG, length=5, sampling_method=method, schedule=schedule,
+                                     kappa=kappa, noise='cpu', use_graph=False).sample((2, 64, 3), cond, label)
+            assert torch.equal(got, want)
+            dh6 = util.calc_diffusion_hyperparams(6, 1e-4, 0.02)
+            torch.manual_seed(4)
+            want = util.sampling(net, (2, 64, 3), dh6, label=label, verbose=False, condition=cond)
+            torch.manual_seed(4)
+            got = GraphedReverseSampler(net, dh6, noise='cpu', use_graph=False).sample((2, 64, 3), cond, label)
+            assert torch.equal(got, want)
+    finally:
+        util.set_device(None)
