@@ -263,7 +263,7 @@ def _random_layer_case(seed, cuda):
             segs.append((U, 0, C, ld, 1, {"V": (V2, 0), "V0": (V2, ld), "ldv": 2 * ld, "nsrc": n_src,
                                             "zrow": B * n_src}))
         else:
-            div = K if (rng.integers(0, 3) == 0 and not gath) else 1
+            div = K if rng.integers(0, 3) == 0 else 1         # neighbour-broadcast segment (also next to a gathered one)
             t = torch.randn(P // div, ld, generator=g)
             cols.append(t[:, :C].repeat_interleave(div, 0))
             segs.append((t.to(cuda), 0, C, ld, div))
@@ -307,7 +307,7 @@ def _random_layer_case(seed, cuda):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("ws", ["1", "0"])
 def test_fused_layer_random_sweep(cuda, ws, monkeypatch):
-    """40 random layer problems through both kernel families (PDR_FUSED_WS is read once per process, so the
+    """60 random layer problems through both kernel families (PDR_FUSED_WS is read once per process, so the
     uniform-wave family is exercised in a child process)."""
     if ws == "0":
         import subprocess, sys, os
@@ -317,7 +317,7 @@ def test_fused_layer_random_sweep(cuda, ws, monkeypatch):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return
     relu_cols = [0, 17, 10 ** 6]
-    for seed in range(40):
+    for seed in range(60):
         act, conv, ref, (B, rpb, Cout) = _random_layer_case(seed, cuda)
         rc0 = relu_cols[seed % 3]
         Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=min(rc0, Cout))
