@@ -128,9 +128,14 @@ __global__ __launch_bounds__(256) void attention_pool_kernel(
     const float sce[4] = {sc.x, sc.y, sc.z, sc.w}, she[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float mn = fmaxf(m[j], se[j]);
-      const float corr = expf(m[j] - mn);      // exp(-inf) = 0 on the first slot
-      const float w = expf(se[j] - mn);
+      // softmax in the base-2 domain: exp(s - m) = exp2((s - m) log2 e) with the hardware v_exp_f32
+      // (two instructions per exponential instead of the ~10 of expf: the kernel was VALU-, not
+      // HBM-limited).  Arguments are <= 0, results in (0, 1]; the rounding of s * log2(e) perturbs
+      // the weights by <= |s - m| * 2^-23 relative.
+      const float s2 = se[j] * 1.44269504088896340736f;
+      const float mn = fmaxf(m[j], s2);
+      const float corr = __builtin_amdgcn_exp2f(m[j] - mn);   // exp2(-inf) = 0 on the first slot
+      const float w = __builtin_amdgcn_exp2f(s2 - mn);
       const float val = fmaxf(__builtin_fmaf(ve[j], sce[j], she[j]), lo);
       l[j] = __builtin_fmaf(l[j], corr, w);
       acc[j] = __builtin_fmaf(acc[j], corr, val * w);

@@ -377,3 +377,30 @@ def test_fused_first_call_runs_the_condition_branch(cuda, cfg_name):
         got3 = fused(x, cond, ts=ts, label=label, use_retained_condition_feature=False)
         close(got3, ref, "unretained eps")
         assert net.encoder_cond_features is None and net.global_feature is None
+
+
+@pytest.mark.parametrize("B,npoint,K,D,ld,use_counts", [(2, 64, 32, 32, 32, True), (3, 100, 8, 64, 72, False),
+                                                        (1, 16, 16, 128, 128, True), (2, 2048, 32, 32, 32, True)])
+def test_attention_pool_matches_masked_softmax(cuda, B, npoint, K, D, ld, use_counts):
+    """pdr_attention_pool == count mask (-1e9), softmax over the K neighbours, weighted sum of
+    relu(values * scale + shift)  (attention.py:83-96), against float64 torch."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + npoint + K)
+    P = B * npoint * K
+    scores = (torch.randn(P, ld, generator=g) * 3).to(cuda)
+    values = torch.randn(P, ld, generator=g).to(cuda)
+    vs, vh = torch.randn(B, D, generator=g).to(cuda), torch.randn(B, D, generator=g).to(cuda)
+    counts = torch.randint(0, K + 1, (B, npoint), generator=g, dtype=torch.int32).to(cuda) if use_counts else None
+    out = torch.empty(B * npoint, D, device=cuda)
+    _lib.check(lib.pdr_attention_pool(scores.data_ptr(), ld, values.data_ptr(), ld, vs.data_ptr(), vh.data_ptr(), 1,
+                                      counts.data_ptr() if use_counts else None, B, npoint, K, D, out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "attention_pool")
+    s = scores[:, :D].double().view(B, npoint, K, D)
+    v = values[:, :D].double().view(B, npoint, K, D)
+    v = (v * vs.double().view(B, 1, 1, D) + vh.double().view(B, 1, 1, D)).relu()
+    if use_counts:
+        c = counts.clamp(min=1).view(B, npoint, 1, 1)
+        mask = torch.arange(K, device=cuda).view(1, 1, K, 1) >= c
+        s = torch.where(mask, torch.full_like(s, -1e9), s)
+    want = (torch.softmax(s, dim=2) * v).sum(2).view(B * npoint, D)
+    assert _rel(out.double(), want) < 2e-6
