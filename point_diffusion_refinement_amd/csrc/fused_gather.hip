@@ -146,6 +146,84 @@ __global__ __launch_bounds__(256) void attention_pool_kernel(
       make_float4(acc[0] / l[0], acc[1] / l[1], acc[2] / l[2], acc[3] / l[3]);
 }
 
+// Wave-per-query form for K * D / 4 <= 64 * NL float4 per query with D / 4 a power of two <= 64: a
+// query's K x D block of scores (and of values) is CONTIGUOUS, so the wave reads it with NL fully
+// coalesced 1-KiB loads each (lane -> (k = e / D4, c4 = e % D4), e = i * 64 + lane) instead of 8
+// separate 128-byte pieces per instruction.  All scores sit in registers: exact two-pass softmax
+// (max, then exp2 / sums), folded across the lanes that share a channel group with xor shuffles.
+template <int NL>
+__global__ __launch_bounds__(256) void attention_pool_wave_kernel(
+    const float* __restrict__ scores, const float* __restrict__ values, const float* __restrict__ vscale,
+    const float* __restrict__ vshift, int v_relu, const int* __restrict__ counts, int K, int D, int npoint,
+    long rows, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int D4 = D >> 2;
+  const int sh = __builtin_ctz(D4);
+  const int c4 = lane & (D4 - 1);
+  const int k0 = lane >> sh;                 // first neighbour of this lane
+  const int kstep = 64 >> sh;                // neighbours covered per load
+  const float lo = v_relu ? 0.0f : -__builtin_inff();
+  const long nwaves = static_cast<long>(gridDim.x) * 4;
+  for (long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const int b = static_cast<int>(row / npoint);
+    int cnt = K;
+    if (counts) {
+      cnt = counts[row];
+      cnt = cnt < 1 ? 1 : cnt;               // attention.py:85 clamp(min=1)
+    }
+    const float4* s4 = reinterpret_cast<const float4*>(scores + row * K * D) + lane;
+    const float4* v4 = reinterpret_cast<const float4*>(values + row * K * D) + lane;
+    float4 sv[NL], vv[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool ok = k0 + i * kstep < K;
+      sv[i] = ok ? s4[i * 64] : make_float4(0, 0, 0, 0);
+      vv[i] = ok ? v4[i * 64] : make_float4(0, 0, 0, 0);
+    }
+    float4 sc = make_float4(1, 1, 1, 1), shv = make_float4(0, 0, 0, 0);
+    if (vscale) sc = *reinterpret_cast<const float4*>(vscale + static_cast<long>(b) * D + 4 * c4);
+    if (vshift) shv = *reinterpret_cast<const float4*>(vshift + static_cast<long>(b) * D + 4 * c4);
+    float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float se[NL][4];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int k = k0 + i * kstep;
+      const float e[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // slots beyond K do not exist (-inf: weight 0); masked slots are exactly -1e9 as in the reference
+        se[i][j] = k >= K ? -__builtin_inff() : (k >= cnt ? -1e9f : e[j]) * 1.44269504088896340736f;
+        m[j] = fmaxf(m[j], se[i][j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      for (int off = D4; off < 64; off <<= 1) m[j] = fmaxf(m[j], __shfl_xor(m[j], off, 64));
+    float l[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+    const float sce[4] = {sc.x, sc.y, sc.z, sc.w}, she[4] = {shv.x, shv.y, shv.z, shv.w};
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float ve[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float w = __builtin_amdgcn_exp2f(se[i][j] - m[j]);
+        const float val = fmaxf(__builtin_fmaf(ve[j], sce[j], she[j]), lo);
+        l[j] += w;
+        acc[j] = __builtin_fmaf(val, w, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      for (int off = D4; off < 64; off <<= 1) {
+        l[j] += __shfl_xor(l[j], off, 64);
+        acc[j] += __shfl_xor(acc[j], off, 64);
+      }
+    if (lane < D4)
+      *reinterpret_cast<float4*>(out + row * D + 4 * c4) =
+          make_float4(acc[0] / l[0], acc[1] / l[1], acc[2] / l[2], acc[3] / l[3]);
+  }
+}
+
 // rows of a channel-last matrix: out[b, j, :] = src[b, idx[b,j], :]
 __global__ __launch_bounds__(256) void gather_rows_cl_kernel(const float* __restrict__ src, int n,
                                                              int C, const int* __restrict__ idx,
@@ -223,6 +301,28 @@ extern "C" int pdr_attention_pool(const float* scores, int lds, const float* val
   if (!scores || !values || !out) return PDR_EINVAL;
   const long rows = static_cast<long>(B) * npoint;
   if (D % 4 || lds % 4 || ldv % 4) return PDR_EUNSUPPORTED;
+  {
+    // wave-per-query form: dense rows (ld == D), D / 4 a power of two <= 64, <= 8 loads per lane
+    const int D4 = D / 4;
+    const long per_query = static_cast<long>(K) * D4;
+    const int kstep = D4 <= 64 ? 64 / (D4 ? D4 : 1) : 0;
+    if (lds == D && ldv == D && D4 <= 64 && (D4 & (D4 - 1)) == 0 && per_query <= 512 && kstep > 0) {
+      const int nl = static_cast<int>((K + kstep - 1) / kstep);
+      long blocks = (rows + 3) / 4;
+      if (blocks > 256L * 16) blocks = 256L * 16;
+      const dim3 grid(static_cast<unsigned>(blocks));
+      hipStream_t st = pdr::as_stream(stream);
+#define PDR_AP(NL)                                                                                      \
+  hipLaunchKernelGGL(attention_pool_wave_kernel<NL>, grid, dim3(256), 0, st, scores, values, vscale,    \
+                     vshift, v_relu, counts, K, D, npoint, rows, out)
+      if (nl <= 1) PDR_AP(1);
+      else if (nl <= 2) PDR_AP(2);
+      else if (nl <= 4) PDR_AP(4);
+      else PDR_AP(8);
+#undef PDR_AP
+      return pdr::check_launch();
+    }
+  }
   hipLaunchKernelGGL(attention_pool_kernel, dim3(blocks_for(rows * (D / 4))), dim3(256), 0,
                      pdr::as_stream(stream), scores, lds, values, ldv, vscale, vshift, v_relu, counts, K,
                      D, npoint, rows, out);

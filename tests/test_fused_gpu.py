@@ -380,7 +380,9 @@ def test_fused_first_call_runs_the_condition_branch(cuda, cfg_name):
 
 
 @pytest.mark.parametrize("B,npoint,K,D,ld,use_counts", [(2, 64, 32, 32, 32, True), (3, 100, 8, 64, 72, False),
-                                                        (1, 16, 16, 128, 128, True), (2, 2048, 32, 32, 32, True)])
+                                                        (1, 16, 16, 128, 128, True), (2, 2048, 32, 32, 32, True),
+                                                        (2, 50, 8, 256, 256, False), (2, 33, 32, 64, 64, True),
+                                                        (1, 7, 8, 8, 8, True), (1, 9, 32, 512, 512, True)])
 def test_attention_pool_matches_masked_softmax(cuda, B, npoint, K, D, ld, use_counts):
     """pdr_attention_pool == count mask (-1e9), softmax over the K neighbours, weighted sum of
     relu(values * scale + shift)  (attention.py:83-96), against float64 torch."""
