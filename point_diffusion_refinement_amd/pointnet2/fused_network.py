@@ -826,11 +826,13 @@ class FusedCloudConditionNet:
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
                         fm_neigh[fm_key(i, blk)] = blk.neighbours(l_uvw[i], l_xyz[i])
+            ev_all = torch.cuda.Event()                 # everything the encoder needs
+            ev_all.record(side)
             for i in range(-1, -(len(self.fp) + 1), -1):
                 d2, idx, _ = _ext.knn_points(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
                 knn[i] = (d2, idx)
-            ev_all = torch.cuda.Event()
-            ev_all.record(side)
+            ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
+            ev_knn.record(side)
 
         # ---- feature path ------------------------------------------------------------------------
         main.wait_event(ev_first)
@@ -843,6 +845,7 @@ class FusedCloudConditionNet:
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)
             centre = gather_rows(sa_in, sels[i])
             l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i]))
+        main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
             mapped = self.dec_map[i](l_uvw[i], dec_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
                                      neigh=fm_neigh[fm_key(i, self.dec_map[i])])
