@@ -787,12 +787,6 @@ class FusedCloudConditionNet:
         xyz = pointcloud[:, :, 0:3].contiguous()
         feat0 = torch.cat([pointcloud[:, :, 3:], xyz / net.scale_factor], dim=2).contiguous() \
             if pointcloud.shape[2] > 3 else (xyz / net.scale_factor)
-        t_emb = None
-        if ts is not None and hp['include_t']:
-            t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
-            t_emb = net.activation(net.fc_t2(t_emb))
-        class_emb = net.class_emb(label)
-        bank.evaluate(t_emb, net.global_feature, class_emb)
         if not self._synced:
             self.sync_condition()
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
@@ -833,6 +827,14 @@ class FusedCloudConditionNet:
                 knn[i] = (d2, idx)
             ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
             ev_knn.record(side)
+
+        # ---- embeddings (independent of the geometry: evaluated while the side stream is already running)
+        t_emb = None
+        if ts is not None and hp['include_t']:
+            t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
+            t_emb = net.activation(net.fc_t2(t_emb))
+        class_emb = net.class_emb(label)
+        bank.evaluate(t_emb, net.global_feature, class_emb)
 
         # ---- feature path ------------------------------------------------------------------------
         main.wait_event(ev_first)
