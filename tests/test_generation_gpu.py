@@ -140,3 +140,40 @@ def test_refine_completion_on_the_fused_network():
     d_got = got - coarse.repeat_interleave(4, 1)
     err = (d_got - d_want).abs() / (d_want.abs() + d_want.abs().max())
     assert float(err.max()) < 1e-2 and float((err < 1e-3).float().mean()) > 0.99, float(err.max())
+
+
+def test_training_step_gradients_match_the_cpu_oracle_path():
+    """train.py:518-533 / the DDPM MSE objective: one backward through the layer-by-layer network uses the HIP
+    backward kernels (gather / group / kNN-gather adjoints); parameter gradients == the same step on the CPU over
+    the oracle's backward restatements."""
+    from tests.golden.tiny_config import tiny_pointnet_config
+    cuda = torch.device("cuda:0")
+    net_cpu = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 51).train()
+    net_gpu = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 51).train().to(cuda)
+    cond, label, gt = _dataset(0, 3)
+    g = torch.Generator().manual_seed(6)
+    x = gt + 0.3 * torch.randn(gt.shape, generator=g)
+    eps = torch.randn(gt.shape, generator=g)
+    ts = torch.tensor([5.0, 900.0, 40.0])
+    loss_gpu = ((net_gpu(x.to(cuda), cond.to(cuda), ts=ts.to(cuda), label=label.to(cuda)) - eps.to(cuda)) ** 2).mean()
+    loss_gpu.backward()
+    with oracle_ops():
+        loss_cpu = ((net_cpu(x, cond, ts=ts, label=label) - eps) ** 2).mean()
+        loss_cpu.backward()
+    assert abs(loss_gpu.item() - loss_cpu.item()) < 1e-4 * abs(loss_cpu.item())
+    # (biases in front of a GroupNorm have an analytically zero gradient: compare against the overall scale too)
+    gmax = max(float(p.grad.abs().max()) for p in net_cpu.parameters() if p.grad is not None)
+    checked = 0
+    for (name, pg), (_, pc) in zip(net_gpu.named_parameters(), net_cpu.named_parameters()):
+        if pc.grad is None:
+            assert pg.grad is None, name
+            continue
+        a, b = pg.grad.cpu().numpy().ravel(), pc.grad.numpy().ravel()
+        # fp32 sums over ~1e4 positions in a different order, ReLU / mask ties: bound the error by the overall
+        # gradient scale, and ask every non-negligible gradient to point the same way
+        assert np.abs(a - b).max() < 2e-3 * gmax, (name, np.abs(a - b).max(), gmax)
+        if np.abs(b).max() > 1e-2 * gmax:
+            cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+            assert cos > 0.9995, (name, cos)
+        checked += 1
+    assert checked > 100
