@@ -49,6 +49,12 @@ FUSE_SCORE_POOL = __import__("os").environ.get("PDR_FUSE_SCORE_POOL", "0") == "1
 # residual columns (a row-wise add in their consumer) are materialised, in the same pass that computes the
 # GroupNorm moments.  Measured on MI355X (B=32, same box): 12.28 ms/step vs 12.58 materialised.  The kNN form
 # carries two extra per-position terms and is always materialised.  PDR_VIRTUAL_FIRST=0 turns it off.
+# Feature-transfer blocks of level >= AHEAD_LEVEL can evaluate their query-independent part (grouping, shared MLP,
+# value conv) on a third stream as soon as the geometry is known.  Measured on MI355X (B=32, same box): OFF 11.65 /
+# 11.71 ms per step, levels >= 2 ahead 12.22 / 12.19, all levels 11.72 / 11.76 -- the persistent layer kernels of the
+# extra stream take workgroup slots (LDS) from the main stream's large kernels and the GPU timeline has no idle gaps
+# to fill (99.8 % covered).  So it is OFF (99); kept as the measured negative result.
+AHEAD_LEVEL = int(__import__("os").environ.get("PDR_AHEAD_LEVEL", "99"))
 # First call of a batch: run the condition branch through the fused blocks too (False: layer-by-layer torch path,
 # what rounds of this code did before; kept for A/B and as the cross-check of the tests).
 FUSE_CONDITION_BRANCH = __import__("os").environ.get("PDR_FUSE_CONDITION_BRANCH", "1") == "1"
@@ -400,8 +406,17 @@ class FusedAttention:
         self.C1, self.C2 = self.q.Cout, att.grouped_feat_conv.weight.shape[0]
         self.D = self.w2.Cout
 
-    def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K):
-        """query: (B*npoint, Cq) tensor; h: Act (value input); key = Y1[:, key_col0:key_col0+C2]."""
+    def values(self, h, B, npoint, K):
+        """Value half (independent of the query features): value conv + its GroupNorm fold."""
+        V, pv, tpv = run_layer(h, self.v, stats=self.v_norm is not None)
+        vs = vt = None
+        if self.v_norm is not None:
+            vs, vt = self.v_norm.fold([(pv, 0, self.D, tpv, 1.0)], B, self.D, npoint * K)
+        return V, vs, vt
+
+    def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None):
+        """query: (B*npoint, Cq) tensor; h: Act (value input); key = Y1[:, key_col0:key_col0+C2];
+        values: result of self.values(h, ...) when it was evaluated ahead of time."""
         lib = _lib.load()
         P = B * npoint * K
         first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
@@ -424,10 +439,7 @@ class FusedAttention:
             S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
-        V, pv, tpv = run_layer(h, self.v, stats=self.v_norm is not None)
-        vs = vt = None
-        if self.v_norm is not None:
-            vs, vt = self.v_norm.fold([(pv, 0, self.D, tpv, 1.0)], B, self.D, npoint * K)
+        V, vs, vt = values if values is not None else self.values(h, B, npoint, K)
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
         cptr = counts.data_ptr() if counts is not None else None
         vsp, vtp = (vs.data_ptr(), vt.data_ptr()) if vs is not None else (None, None)
@@ -604,7 +616,10 @@ class FusedGroupedBlock:
     def neighbours(self, src_xyz, new_xyz):
         return _ext.ball_query(new_xyz, src_xyz, self.radius, self.nsample)
 
-    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None):
+    def prepare(self, src_xyz, src_feats_cl, new_xyz, bank, subset, neigh=None):
+        """Everything that does not involve the QUERY features: grouping, the shared MLP and the value half of the
+        attention.  For the feature-transfer blocks this depends on coordinates and static tables only, so it can
+        run ahead of the feature path on another stream."""
         B, m, _ = new_xyz.shape
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
         K = self.nsample
@@ -619,8 +634,17 @@ class FusedGroupedBlock:
             G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
                                 self.with_centre)
             h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K, C=Cg), bank)
-        out = self.att(query_feats_cl.reshape(B * m, -1), h, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K)
+        return dict(h=h, Y1=Y1, part1=part1, tpb1=tpb1, counts=counts, B=B, m=m, K=K,
+                    values=self.att.values(h, B, m, K))
+
+    def finish(self, prep, query_feats_cl):
+        B, m, K = prep["B"], prep["m"], prep["K"]
+        out = self.att(query_feats_cl.reshape(B * m, -1), prep["h"], prep["Y1"], prep["part1"], prep["tpb1"],
+                       self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"])
         return out.view(B, m, -1)
+
+    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None):
+        return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh), query_feats_cl)
 
 
 class FusedKnnFP:
@@ -708,6 +732,11 @@ class FusedCloudConditionNet:
         if self._side is None:
             self._side = torch.cuda.Stream(device=next(self.net.parameters()).device)
         return self._side
+
+    def _aux_stream(self):
+        if getattr(self, "_aux", None) is None:
+            self._aux = torch.cuda.Stream(device=next(self.net.parameters()).device)
+        return self._aux
 
     def sync_condition(self):
         """Channel-last copies of the retained condition features.  Called once per batch, after the
@@ -820,6 +849,8 @@ class FusedCloudConditionNet:
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
                         fm_neigh[fm_key(i, blk)] = blk.neighbours(l_uvw[i], l_xyz[i])
+            for t in l_xyz:                             # 16-byte padded coordinates of every level (shared by
+                xyz4(t)                                 # all streams: produced here, before ev_all)
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
             for i in range(-1, -(len(self.fp) + 1), -1):
@@ -836,12 +867,35 @@ class FusedCloudConditionNet:
         class_emb = net.class_emb(label)
         bank.evaluate(t_emb, net.global_feature, class_emb)
 
+        # ---- query-independent parts of the deep feature-transfer blocks, ahead of time on a third stream
+        ahead = {}
+        if AHEAD_LEVEL <= nlev:
+            ev_bank = torch.cuda.Event()
+            ev_bank.record(main)
+            aux = self._aux_stream()
+            aux.wait_event(ev_all)
+            aux.wait_event(ev_bank)
+            todo = [(self.enc_map[l], l, enc_cl) for l in range(AHEAD_LEVEL, nlev)] + \
+                   [(self.dec_map[l], l, dec_cl) for l in range(nlev, AHEAD_LEVEL - 1, -1)]
+            with torch.cuda.stream(aux):
+                for blk, l, cl in todo:
+                    prep = blk.prepare(l_uvw[l], cl[l], l_xyz[l], bank, subset=False, neigh=fm_neigh[fm_key(l, blk)])
+                    ev = torch.cuda.Event()
+                    ev.record(aux)
+                    ahead[id(blk)] = (prep, ev)
+
+        def transfer(blk, l, cl, query):
+            hit = ahead.pop(id(blk), None)
+            if hit is not None:
+                main.wait_event(hit[1])
+                return blk.finish(hit[0], query)
+            return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)])
+
         # ---- feature path ------------------------------------------------------------------------
         main.wait_event(ev_first)
         l_feat = [feat0]
         for i, sa in enumerate(self.sa):
-            mapped = self.enc_map[i](l_uvw[i], enc_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
-                                     neigh=fm_neigh[fm_key(i, self.enc_map[i])])
+            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i])
             if i == 0:
                 main.wait_event(ev_all)
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)
@@ -849,12 +903,11 @@ class FusedCloudConditionNet:
             l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i]))
         main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
-            mapped = self.dec_map[i](l_uvw[i], dec_cl[i], l_xyz[i], l_feat[i], bank, subset=False,
-                                     neigh=fm_neigh[fm_key(i, self.dec_map[i])])
+            mapped = transfer(self.dec_map[i], i % (nlev + 1), dec_cl, l_feat[i])
             fp_in = torch.cat([mapped, l_feat[i]], dim=2)
             l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i])
-        mapped = self.dec_map[0](l_uvw[0], dec_cl[0], l_xyz[0], l_feat[0], bank, subset=False,
-                                 neigh=fm_neigh[fm_key(0, self.dec_map[0])])
+        mapped = transfer(self.dec_map[0], 0, dec_cl, l_feat[0])
+        assert not ahead
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz4(xyz), 0, 3, 4, 1)], B * N, B, N)
         Y, part, tpb = run_layer(head_in, self.head1, stats=True)
