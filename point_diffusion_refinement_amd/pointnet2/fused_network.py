@@ -838,6 +838,8 @@ class FusedCloudConditionNet:
 
         with torch.cuda.stream(side):
             fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
+            if AHEAD_LEVEL == 0:
+                xyz4(xyz)
             ev_first = torch.cuda.Event()
             ev_first.record(side)
             for i, sa in enumerate(self.sa):
@@ -849,8 +851,12 @@ class FusedCloudConditionNet:
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
                         fm_neigh[fm_key(i, blk)] = blk.neighbours(l_uvw[i], l_xyz[i])
-            for t in l_xyz:                             # 16-byte padded coordinates of every level (shared by
-                xyz4(t)                                 # all streams: produced here, before ev_all)
+            if AHEAD_LEVEL <= nlev:
+                # the third stream reads the 16-byte padded coordinates too: produce them HERE (ordered before
+                # ev_all for every consumer) instead of lazily on whichever stream asks first.  Level 0 is used
+                # by the main stream right after ev_first, so it stays lazy (main) unless it is needed ahead.
+                for t in l_xyz[1:]:
+                    xyz4(t)
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
             for i in range(-1, -(len(self.fp) + 1), -1):

@@ -16,6 +16,7 @@ SHAPES = [  # (rows per batch element, Cin, Cout) at B = 32
     (16384, 128, 128), (16384, 171, 128), (8192, 128, 128), (8192, 331, 128), (2048, 256, 256), (2048, 331, 256),
     (512, 512, 512), (512, 651, 256), (65536, 32, 32), (32768, 64, 64), (65536, 41, 32), (8192, 64, 128),
     (4096, 512, 512), (16384, 512, 512), (16384, 256, 256),   # steady-state probes (not network shapes)
+    (512, 128, 128), (512, 64, 64), (2048, 64, 64), (2048, 128, 128), (512, 256, 256), (128, 512, 512),  # deep levels
 ]
 
 
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--zeros", action="store_true", help="zero operands (DVFS probe: data-dependent power)")
     ap.add_argument("--only", type=int, default=None, help="index into SHAPES")
+    ap.add_argument("--first", type=int, default=0, help="skip SHAPES before this index")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = args.lib
@@ -34,7 +36,7 @@ def main():
     B = args.batch
     st = torch.cuda.current_stream().cuda_stream
     tot = 0.0
-    for rpb, Cin, Cout in (SHAPES if args.only is None else [SHAPES[args.only]]):
+    for rpb, Cin, Cout in (SHAPES[args.first:] if args.only is None else [SHAPES[args.only]]):
         P = B * rpb
         ldx = (Cin + 3) // 4 * 4
         X = torch.randn(P, ldx, device=dev)
