@@ -215,6 +215,12 @@ int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
 /* index of the kernel instantiation used for this shape: 0 256x32, 1 256x64, 2 128x96, 3 128x160,
  * 4 128x128 (2-D grid), 5 64x128, 6 32x128 */
 int pdr_fused_layer_variant(int rows_per_batch, int Cout);
+/* The launch pdr_fused_layer would make for these arguments, without launching (profilers attribute a call
+ * to its kernel symbol): out[0..5] = {wave-specialised kernel (csrc/fused_layer_ws.hip)?, tile variant id,
+ * residual source?, gathered source?, float4 staging?, split-bf16 arithmetic?}.  Same return codes as
+ * pdr_fused_layer.  Process-wide tuning knob read once: PDR_FUSED_WS=0 selects the uniform-wave kernels. */
+int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw, int Cout,
+                         const float *Y, int ldy, int *out);
 /* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight
  * transposed; 16-B aligned, leading dimension ldw >= Cout with ldw % 4 == 0), exact fp32 MFMA.
  * Sources whose pointers are 16-B aligned and whose leading dimensions are multiples of 4 floats

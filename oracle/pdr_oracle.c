@@ -357,6 +357,10 @@ int pdr_oracle_knn_grad(const float *x, const float *y, const int64_t *idx,
  * match (B,m,n) indexed [(l)*n + k]; launch <<<32,512>>>: the per-thread
  * accumulation order over l (pass 1, 3) and k (pass 2) is sequential and is
  * reproduced here; __expf is restated as expf (GPU parity tolerance 1e-4).
+ * Contraction (model N1, as in matchcost below): the single-use products of
+ * passes 1 and 2 (`w = e*r; sum += w`, :79-80, :108-110) are fused multiply-adds;
+ * pass 3's `w` (:147-149) has two uses (match += w, suml += w) and stays a
+ * separately rounded product.
  */
 int pdr_oracle_approxmatch(const float *xyz1, const float *xyz2, int B, int n,
                            int m, float *match) {
@@ -384,7 +388,8 @@ int pdr_oracle_approxmatch(const float *xyz1, const float *xyz2, int B, int n,
           const float dx = p2[l * 3] - x1, dy = p2[l * 3 + 1] - y1,
                       dz = p2[l * 3 + 2] - z1;
           const float d = level * PDR_SUM3(dx, dy, dz);
-          suml += expf(d) * remainR[l];
+          /* `w = __expf(d)*buf; suml += w` (:79-80): w has one use -> contracted (model N1) */
+          suml = fmaf(expf(d), remainR[l], suml);
         }
         ratioL[k] = remainL[k] / suml;
       }
@@ -394,7 +399,8 @@ int pdr_oracle_approxmatch(const float *xyz1, const float *xyz2, int B, int n,
         for (int k = 0; k < n; ++k) {
           const float dx = x2 - p1[k * 3], dy = y2 - p1[k * 3 + 1],
                       dz = z2 - p1[k * 3 + 2];
-          sumr += expf(level * PDR_SUM3(dx, dy, dz)) * ratioL[k];
+          /* :108-110, single-use product -> contracted (model N1) */
+          sumr = fmaf(expf(level * PDR_SUM3(dx, dy, dz)), ratioL[k], sumr);
         }
         sumr *= remainR[l];
         const float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);

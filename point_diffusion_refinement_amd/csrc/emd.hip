@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void emd_pass1_kernel(const float* __restrict_
       const float4 t = tile[l];
       const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
       const float d = level * PDR_SUM3(dx, dy, dz);
-      suml += __expf(d) * t.w;
+      suml = __builtin_fmaf(__expf(d), t.w, suml);   // single-use product: contracted (model N1)
     }
   }
   if (k < n) w.ratioL[static_cast<size_t>(li) * n + k] = w.remainL[k] / suml;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void emd_pass2_kernel(const float* __restrict_
     for (int k = 0; k < kend; ++k) {
       const float4 t = tile[k];
       const float dx = x2 - t.x, dy = y2 - t.y, dz = z2 - t.z;
-      sumr += __expf(level * PDR_SUM3(dx, dy, dz)) * t.w;
+      sumr = __builtin_fmaf(__expf(level * PDR_SUM3(dx, dy, dz)), t.w, sumr);   // model N1
     }
   }
   if (l < m) {

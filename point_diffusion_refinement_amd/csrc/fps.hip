@@ -193,12 +193,11 @@ int launch_resident(const float* xyz, int B, int N, int m, int R, int Rbits, int
                     int* idx, hipStream_t s) {
   const size_t lds = static_cast<size_t>((3 * N + 3) & ~3) * sizeof(float) +
                      2 * (T / 64) * sizeof(unsigned long long);
-  static bool attr_set = false;  // benign race: idempotent
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_resident_kernel<T, PPT>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  // the attribute is per DEVICE: set it on every large launch (cheap host call, no global state), checked
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_resident_kernel<T, PPT>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return PDR_ELAUNCH;
   hipLaunchKernelGGL((fps_resident_kernel<T, PPT>), dim3(B), dim3(T), lds, s, xyz, N, m, R,
                      Rbits, Q, idx);
   return pdr::check_launch();

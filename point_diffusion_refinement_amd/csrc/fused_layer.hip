@@ -718,18 +718,32 @@ extern "C" int pdr_fused_layer_variant(int rows_per_batch, int Cout) {
   return pick_tile(rows_per_batch, Cout).id;
 }
 
-// Y (P, Cout; leading dim ldy) = prologue(X) . Wt + bias.  partial: NULL or
-// (B * tiles_per_batch, Cout, 2) floats receiving per-tile sum / sum of squares of y
-// (columns >= relu_col0: of relu(y)).
-extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
-                               const float* bias, int Cout, float* Y, int ldy, float* partial,
-                               int relu_col0, pdr_stream_t stream) {
-  if (!in || !Wt || !Y || P < 0 || Cin <= 0 || Cout <= 0 || in->n_seg < 1 || in->n_seg > 4 ||
-      ldw < Cout || ldy < Cout)
+// The dispatch decision of pdr_fused_layer, shared with pdr_fused_layer_plan (profilers / bench.py attribute a
+// call to the kernel symbol it launches without duplicating these rules).
+namespace {
+struct LayerPlan {
+  TileCfg t;
+  bool vec, gath, radd, ws;
+  long ntiles;
+  int ncol;
+};
+
+bool use_ws_kernels() {
+  // tuning knob, read ONCE per process: PDR_FUSED_WS=0 selects the uniform-wave kernels (documented in pdr_hip.h)
+  static const bool use_ws = []() {
+    const char* e = getenv("PDR_FUSED_WS");
+    return !(e && e[0] == '0');
+  }();
+  return use_ws;
+}
+
+int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw, int Cout, const float* Y,
+               int ldy, LayerPlan* pl) {
+  if (!in || !Wt || P < 0 || Cin <= 0 || Cout <= 0 || in->n_seg < 1 || in->n_seg > 4 || ldw < Cout ||
+      (Y && ldy < Cout))
     return PDR_EINVAL;
   // the weight matrix is staged with 16-B loads: packed with a 4-float-aligned leading dimension
   if (ldw % 4 != 0 || reinterpret_cast<uintptr_t>(Wt) % 16 != 0) return PDR_EINVAL;
-  if (P == 0) return PDR_OK;
   int ctot = 0;
   for (int s = 0; s < in->n_seg; ++s) {
     if (!in->seg[s].ptr || in->seg[s].C <= 0 || in->seg[s].row_div < 1) return PDR_EINVAL;
@@ -746,16 +760,10 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     const int d = in->seg[sg].row_div;
     if (in->rows_per_batch % d != 0 || (in->rows_per_batch > t.tm && t.tm % d != 0)) return PDR_EUNSUPPORTED;
   }
-  hipStream_t s = pdr::as_stream(stream);
   const long nb = P / in->rows_per_batch;
-  const long ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
-  const int ncol = (Cout + t.tn - 1) / t.tn;
-  // enough workgroups to fill 256 CUs a few times over; the rest is covered by the grid stride
-  long gx = ntiles;
-  const long cap = (256L * 6 + ncol - 1) / ncol;
-  if (gx > cap) gx = cap;
-  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
-  const int nt = static_cast<int>(ntiles);
+  pl->t = t;
+  pl->ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
+  pl->ncol = (Cout + t.tn - 1) / t.tn;
   // vector (float4) A staging needs every source 16-B aligned with a leading dimension that is a
   // multiple of 4 floats and rows padded to a multiple of 4 channels
   auto aligned = [](const float* p, int ld, int C) {
@@ -789,12 +797,55 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     for (int sg = 0; sg < in->n_seg; ++sg)
       if (in->seg[sg].gV && in->gcnt && !in->seg[sg].gV0) return PDR_EINVAL;
   }
-  // steady-state layers (float4-staged, no gathered source): wave-specialised kernel
-  static const bool use_ws = []() {
-    const char* e = getenv("PDR_FUSED_WS");   // tuning knob: PDR_FUSED_WS=0 selects the uniform-wave kernel
-    return !(e && e[0] == '0');
-  }();
-  if (use_ws && vec &&
+  pl->vec = vec;
+  pl->gath = gath;
+  pl->radd = radd;
+  // steady-state layers (float4-staged sources): wave-specialised kernel where an instantiation exists
+  pl->ws = use_ws_kernels() && vec && pdr::fused_layer_ws_supported(t.id, radd, gath, *in, Cin);
+  return PDR_OK;
+}
+}  // namespace
+
+// out[0..5] = {wave-specialised kernel?, tile variant id, residual source?, gathered source?, float4 staging?,
+// split-bf16 arithmetic?} of the launch pdr_fused_layer would make for these arguments.
+extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw, int Cout,
+                                    const float* Y, int ldy, int* out) {
+  if (!out) return PDR_EINVAL;
+  LayerPlan pl;
+  const int rc = plan_layer(in, P, Cin, Wt, ldw, Cout, Y, ldy, &pl);
+  if (rc != PDR_OK) return rc;
+  out[0] = pl.ws;
+  out[1] = pl.t.id;
+  out[2] = pl.radd;
+  out[3] = pl.gath;
+  out[4] = pl.vec;
+  out[5] = 0;
+  return PDR_OK;
+}
+
+// Y (P, Cout; leading dim ldy) = prologue(X) . Wt + bias.  partial: NULL or
+// (B * tiles_per_batch, Cout, 2) floats receiving per-tile sum / sum of squares of y
+// (columns >= relu_col0: of relu(y)).
+extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
+                               const float* bias, int Cout, float* Y, int ldy, float* partial,
+                               int relu_col0, pdr_stream_t stream) {
+  if (!Y) return PDR_EINVAL;
+  LayerPlan pl;
+  const int prc = plan_layer(in, P, Cin, Wt, ldw, Cout, Y, ldy, &pl);
+  if (prc != PDR_OK) return prc;
+  if (P == 0) return PDR_OK;
+  const TileCfg t = pl.t;
+  const bool vec = pl.vec, gath = pl.gath, radd = pl.radd;
+  hipStream_t s = pdr::as_stream(stream);
+  const long ntiles = pl.ntiles;
+  const int ncol = pl.ncol;
+  // enough workgroups to fill 256 CUs a few times over; the rest is covered by the grid stride
+  long gx = ntiles;
+  const long cap = (256L * 6 + ncol - 1) / ncol;
+  if (gx > cap) gx = cap;
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
+  const int nt = static_cast<int>(ntiles);
+  if (pl.ws &&
       pdr::launch_fused_layer_ws(t.id, radd, gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt,
                                  ncol, s))
     return pdr::check_launch();

@@ -607,12 +607,10 @@ extern "C" int pdr_lab_trace_read(unsigned long long* dst) {
 
 namespace pdr {
 
-// Launches the wave-specialised kernel for tile variant `id` (pick_tile() of fused_layer.hip).
-// Returns false when the variant has no wave-specialised instantiation.
-bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
-                           int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
-                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s) {
+// Whether tile variant `id` (pick_tile() of fused_layer.hip) has a wave-specialised instantiation for this input.
+bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin) {
   if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
+  if (id == 3 || id > 5) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
   if (gath) {
     // gathered sources here: plain residual only; empty balls through the table's zero row and a V0
     // that sits a small non-negative offset behind V (one allocation)
@@ -627,6 +625,15 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
       }
     }
   }
+  return true;
+}
+
+// Launches the wave-specialised kernel for tile variant `id`.  Returns false when the variant has no
+// wave-specialised instantiation.
+bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
+                           int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
+                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s) {
+  if (!fused_layer_ws_supported(id, radd, gath, in, Cin)) return false;
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   const long cap = (512 + ncol - 1) / ncol;

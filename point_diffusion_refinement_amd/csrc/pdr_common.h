@@ -30,6 +30,7 @@ inline int check_launch() {
 inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // fused_layer_ws.hip: wave-specialised layer kernel; false = no instantiation for this tile variant
+bool fused_layer_ws_supported(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin);
 bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,
                            const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
                            float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s);

@@ -46,10 +46,14 @@ class GradientAllReduce:
         self._pending = [len(items) for _, items in self.buckets]
         self._handles = []
         self._queued = False
+        self._next = 0
+        self._fired = set()
         for p in params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _close(self, params):
+        assert all(p.dtype == params[0].dtype and p.device == params[0].device for p in params), \
+            "a gradient bucket holds parameters of one dtype on one device"
         total = sum(p.numel() for p in params)
         flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
         items, off = [], 0
@@ -62,23 +66,32 @@ class GradientAllReduce:
         bi, off, n = self._where[p]
         flat, items = self.buckets[bi]
         flat.narrow(0, off, n).copy_(p.grad.reshape(-1))
+        self._fired.add(p)
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:                              # bucket complete: start its ring transfer now
-            self._handles.append((bi, dist.all_reduce(flat, group=self.group, async_op=True)))
+        # a complete bucket starts its ring transfer now -- in BUCKET ORDER (collectives are matched across
+        # ranks by issue order, so every rank must launch 0, 1, 2, ... whatever order its hooks fire in)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
         if not self._queued:                                    # once per backward: finish after the engine is done
             self._queued = True
             Variable._execution_engine.queue_callback(self.synchronize)
 
+    def _launch(self, bi):
+        flat, items = self.buckets[bi]
+        if self._pending[bi] > 0:                               # parameters without a gradient contribute zeros
+            for p, off, n in items:
+                if p not in self._fired:                       # (also covers a stale .grad of an earlier step)
+                    flat.narrow(0, off, n).zero_()
+        self._handles.append((bi, dist.all_reduce(flat, group=self.group, async_op=True)))
+        self._next = bi + 1
+
     def synchronize(self):
         """Wait for the outstanding all-reduces; write the averaged gradients back."""
-        # parameters that received no gradient this step leave their bucket incomplete: reduce it as it is
-        launched = {bi for bi, _ in self._handles}
-        for bi, (flat, items) in enumerate(self.buckets):
-            if bi not in launched and self._pending[bi] < len(items):
-                for p, off, n in items:
-                    if p.grad is None:
-                        flat.narrow(0, off, n).zero_()
-                self._handles.append((bi, dist.all_reduce(flat, group=self.group, async_op=True)))
+        # EVERY bucket is reduced on EVERY rank once a backward has run (participation must not depend on which
+        # parameters happened to receive a gradient on this rank: another rank may have produced one, and ranks
+        # issuing different numbers of collectives hang).  Parameters without a gradient contribute zeros.
+        while self._next < len(self.buckets):
+            self._launch(self._next)
         for bi, h in self._handles:
             h.wait()
             flat, items = self.buckets[bi]
@@ -89,6 +102,8 @@ class GradientAllReduce:
         self._handles = []
         self._pending = [len(items) for _, items in self.buckets]
         self._queued = False
+        self._next = 0
+        self._fired = set()
 
 
 def apply_gradient_allreduce(module, bucket_bytes=8 << 20, group=None):

@@ -166,9 +166,11 @@ def xyz4(t):
     key = (t.data_ptr(), tuple(t.shape))
     hit = _XYZ4.get(key)
     if hit is None:
-        hit = torch.nn.functional.pad(t, (0, -t.shape[-1] % 4)).contiguous()
+        # the entry holds the SOURCE too: while it lives, the allocator cannot hand the source's address to
+        # another same-shape tensor, so a key can never alias a different tensor within one forward
+        hit = (t, torch.nn.functional.pad(t, (0, -t.shape[-1] % 4)).contiguous())
         _XYZ4[key] = hit
-    return hit
+    return hit[1]
 
 
 def plain(t2d, B, rows_per_batch, row_div=1, C=None):
@@ -691,8 +693,15 @@ class FusedKnnFP:
 class FusedCloudConditionNet:
     """Cached-condition forward of PointNet2CloudCondition through the fused kernels."""
 
-    def __init__(self, net):
+    def __init__(self, net, precision="f32"):
+        """precision: "f32" (default; every GEMM on the exact fp32 MFMA) or "split_bf16" (opt-in: GEMMs with
+        Cin >= 128 split both operands into bf16 hi + lo parts and run 3 bf16 MFMAs with fp32 accumulation)."""
         hp = net.hparams
+        if precision not in ("f32", "split_bf16"):
+            raise ValueError("precision must be 'f32' or 'split_bf16'")
+        self.precision = precision
+        if net.scale_factor != 1:
+            raise NotImplementedError("fused path: scale_factor == 1 (coordinates are not rescaled here)")
         if not (net.include_local_feature and net.include_global_feature and hp['include_class_condition']
                 and net.attach_position_to_input_feature and net.bn and not hp['bn_first']
                 and net.network_activation == 'relu'):

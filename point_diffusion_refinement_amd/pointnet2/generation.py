@@ -66,12 +66,13 @@ def refine_completion(refine_net, generated, condition, label, output_scale_fact
     return generated + displacement * output_scale_factor
 
 
-def gather_records(records, group=None):
+def gather_records(records, group=None, return_counts=False):
     """All ranks' (n_r, C) records concatenated in rank order -> (sum n_r, C) on every rank.
     Shards may have different lengths (last rank short): lengths are exchanged first and the
-    payload is padded to the longest shard -- two tiny collectives for the whole job."""
+    payload is padded to the longest shard -- two tiny collectives for the whole job.
+    return_counts: also return [n_0, ..., n_{W-1}] (how many records each rank contributed)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return records
+        return (records, [int(records.shape[0])]) if return_counts else records
     world = dist.get_world_size(group)
     n = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
@@ -82,7 +83,8 @@ def gather_records(records, group=None):
     padded[:records.shape[0]] = records
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    everything = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    return (everything, counts) if return_counts else everything
 
 
 def summarize(all_records):
@@ -93,9 +95,12 @@ def summarize(all_records):
 
 
 def generate_and_evaluate(generate, dataset, num_shapes, batch_size, rank=0, world_size=1, scale=1.0,
-                          compute_emd=True, group=None):
+                          compute_emd=True, group=None, device=None):
     """Run this rank's shard.  `dataset(lo, hi)` -> (condition, label, gt) for partial indices [lo, hi)
     (gt already expanded per partial view: gt_idx = index // 26, mvp_dataset.py:289).
+    `device`: where an EMPTY shard's (0,5) record tensor lives (a rank past the end of the data still takes part
+    in the collective, and under RCCL every rank must hand over a tensor on its own GPU); defaults to the
+    current CUDA device when the process group's backend is nccl, else the CPU.
     Returns (local generated clouds, ALL ranks' records in rank order, summary)."""
     first, last, _, _ = rank_shard(num_shapes, rank, world_size)
     clouds, recs = [], []
@@ -104,6 +109,12 @@ def generate_and_evaluate(generate, dataset, num_shapes, batch_size, rank=0, wor
         g, r = evaluate_batch(generate, condition, label, gt, scale=scale, compute_emd=compute_emd)
         clouds.append(g)
         recs.append(r)
-    local = torch.cat(recs, 0) if recs else torch.zeros((0, 5))
+    if recs:
+        local = torch.cat(recs, 0)
+    else:
+        if device is None and dist.is_available() and dist.is_initialized() and \
+                dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())
+        local = torch.zeros((0, 5), dtype=torch.float32, device=device)
     everything = gather_records(local, group=group)
     return (torch.cat(clouds, 0) if clouds else None), everything, summarize(everything)

@@ -232,7 +232,9 @@ def group_knn(x, y, features_at_y, K, transpose=False):
     """
     feats_y = features_at_y.transpose(1, 2).contiguous() if transpose else features_at_y
     d2, idx, nn_abs = _ext.knn_points(x, y, K, return_nn=True)
-    neigh = knn_gather(feats_y, idx)
+    # K > N2: knn_points pads missing neighbours with idx -1 (dist 0, nn 0).  pytorch3d zero-initialises idx, so
+    # the reference's knn_gather reads row 0 there; clamp to reproduce that instead of an out-of-range gather.
+    neigh = knn_gather(feats_y, idx.clamp(min=0))
     x_rep = x.unsqueeze(2).repeat(1, 1, K, 1)
     nn_rel = nn_abs - x_rep
     d2 = d2.unsqueeze(3)

@@ -43,3 +43,17 @@ def metric_clouds():
     gt = torch.rand(3, 256, 3, generator=g) - 0.5
     gen = gt[:, torch.randperm(256, generator=g)] + 0.02 * torch.randn(3, 256, 3, generator=g)
     return gen.contiguous(), gt.contiguous()
+
+
+def ddpm_inputs(B=1, N=2048, M=3072):
+    """Full-size single cloud of the BASELINE shape contract (configs[0]): x_t (1,2048,3) ~ N(0,1), condition
+    (1,3072,4) mirrored halves with the +-1 flag, ts = 500, label = 5."""
+    g = _gen(5)
+    x = torch.randn(B, N, 3, generator=g)
+    half = torch.rand(B, M // 2, 3, generator=g) * 2 - 1
+    mirrored = half * torch.tensor([1.0, 1.0, -1.0])
+    cond = torch.cat([torch.cat([half, torch.ones(B, M // 2, 1)], 2),
+                      torch.cat([mirrored, -torch.ones(B, M // 2, 1)], 2)], 1)
+    ts = torch.full((B,), 500.0)
+    label = torch.full((B,), 5, dtype=torch.long)
+    return x.contiguous(), cond.contiguous(), ts, label

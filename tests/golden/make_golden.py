@@ -136,6 +136,18 @@ def network():
     save("network_tiny.npz", **out)
 
 
+def network_ddpm():
+    """ONE full-size forward of the reference network on the shipped DDPM architecture (B=1, N=2048, 3072-point
+    condition; first call with retention, then a cached call), deterministic weights."""
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    x, cond, ts, label = I.ddpm_inputs()
+    net = fill_deterministic(PointNet2CloudCondition(R.load_config()['pointnet_config']), 31).eval()
+    with torch.no_grad():
+        first = net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        cached = net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+    save("network_ddpm.npz", eps_first=first, eps_cached=cached)
+
+
 def schedules():
     from util import calc_diffusion_hyperparams
     import util_fastdpmv2 as F
@@ -199,6 +211,7 @@ def state_dict_keys():
 if __name__ == "__main__":
     layers()
     network()
+    network_ddpm()
     schedules()
     metrics()
     mirror()

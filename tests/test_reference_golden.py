@@ -153,6 +153,33 @@ def _quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+def test_full_ddpm_config_forward_matches_reference(be):
+    """The shipped DDPM architecture at FULL size (B=1, N=2048, 3072-point condition; 9.76 M parameters): the
+    reference network's first (retaining) and cached forward, generated by tests/golden/make_golden.py
+    network_ddpm() from the imported reference.  cpu-oracle: the product network over the same oracle ops is
+    BIT-IDENTICAL (same ops, same order).  hip: layer-by-layer network over libpdr_hip.so, and the fused
+    channel-last network, within the network-level bar."""
+    from point_diffusion_refinement_amd.pointnet2.configs import ddpm_pointnet_config
+    g = gold("network_ddpm.npz")
+    x, cond, ts, label = be.to(*I.ddpm_inputs())
+    net = fill_deterministic(PointNet2CloudCondition(ddpm_pointnet_config()), 31).eval().to(be.device)
+    with torch.no_grad(), be.ops():
+        first = net(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        cached = net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+    if be.kind == "cpu-oracle":
+        assert np.array_equal(first.numpy(), g["eps_first"]) and np.array_equal(cached.numpy(), g["eps_cached"])
+        return
+    be.net_close(first, g["eps_first"])
+    be.net_close(cached, g["eps_cached"])
+    from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
+    fused = FusedCloudConditionNet(net)
+    net.reset_cond_features()
+    with torch.no_grad():
+        be.net_close(fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"])
+        be.net_close(fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True),
+                     g["eps_cached"])
+
+
 def test_network_forward_caching_and_samplers(be):
     g = gold("network_tiny.npz")
     x, cond, ts, label = be.to(*I.network_inputs())

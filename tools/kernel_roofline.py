@@ -1,81 +1,179 @@
 """Live roofline of the dominant hand-written kernel of the reverse step (used by bench.py).
 
-The dominant kernel (largest share of the step in profiles/*_kernel_stats.csv) is
-`fused_layer_ws_kernel<2,2,2,2,32,false,false>`: the wave-specialised 128 x 128-tile fp32-MFMA layer kernel
-(csrc/fused_layer_ws.hip) that evaluates the wide 1x1-conv GEMMs of the SA / feature-transfer /
-kNN-FP blocks.  Its roof is the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
-
-Every launch of that instantiation inside a reverse step is bracketed with HIP events recorded on
-the stream the kernel is launched on (torch's current stream; the ops read the same stream handle),
-over `reps` eager repetitions of the step:
-    achieved = (sum of algorithmic flops of those launches) / (sum of their durations)
-           = (average algorithmic flops per launch) / (average launch duration)
-with algorithmic flops of a launch = 2 * P * Cin * Cout (P positions, no padding counted).
+Nothing here is hard-coded to a kernel: every C-ABI launch of `reps` eager repetitions of the step is
+bracketed with HIP events recorded on the stream the kernel is launched on (torch's current stream -- the
+ops read the same stream handle), launches are grouped by the kernel SYMBOL they dispatch to
+(`pdr_fused_layer_plan` returns the instantiation `pdr_fused_layer` picks for a call) and the group with the
+largest total time is the dominant kernel of THIS run.  For it
+    achieved = (sum of algorithmic flops [or bytes] of its launches) / (sum of their durations)
+with the algorithmic work of a launch stated per entry point in `_work()` (no padding, no re-reads):
+    pdr_fused_layer     2 P Cin Cout flops;  4 (sum_seg C P / row_div + P Cout [+ P Cin residual]) bytes
+    pdr_gather_add      table + query rows + index + written columns
+    pdr_attention_pool  8 D P bytes in, 4 D P / K out
+and the roof is the one that binds that kernel: max(flops / 157.3 TF, bytes / 8 TB/s).
+`traffic` (HBM bytes per launch from the PMC passes of tools/profile_round.sh) is looked up BY THE SELECTED
+SYMBOL in the newest profiles/r*_pmc_traffic.json; a profile that does not contain the symbol is reported as
+an error string instead of a stale number.
 """
+import collections
+import glob
 import json
 import os
+import re
 
 import torch
 
 from point_diffusion_refinement_amd import _lib
-from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
 
-DOMINANT_VARIANT = 4          # pdr_fused_layer_variant(): 128 x 128 tile, 2-D grid
-DOMINANT_SYMBOL = "fused_layer_ws_kernel<2, 2, 2, 2, 32, false, false>"
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# tile variants of pdr_fused_layer (csrc/fused_layer.hip pick_tile / launch tables): id -> <RT, CT, WR, WC, KC>
+_VARIANT = {0: (2, 1, 4, 1, 16), 1: (2, 2, 4, 1, 16), 2: (1, 3, 4, 1, 32), 3: (1, 5, 4, 1, 32), 4: (2, 2, 2, 2, 32),
+            5: (1, 2, 2, 2, 32), 6: (1, 1, 1, 4, 32)}
 
 
-TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                            "r1_pmc_traffic.json")
+def _b(x):
+    return "true" if x else "false"
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh: FETCH_SIZE
-    and WRITE_SIZE in separate rocprofv3 runs of this bench, FETCH_SIZE doubled per the gfx950 correction), or None."""
-    try:
-        for k in json.load(open(TRAFFIC_FILE))["kernels"]:
-            if DOMINANT_SYMBOL in k["kernel"]:
-                return k["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+def _layer_symbol(plan):
+    ws, vid, radd, gath, vec, split = plan
+    t = ", ".join(str(v) for v in _VARIANT[vid])
+    if ws and split:
+        return "fused_layer_ws_bf16x3_kernel<%s, %s, %s>" % (t, _b(radd), _b(gath))
+    if ws:
+        return "fused_layer_ws_kernel<%s, %s, %s>" % (t, _b(radd), _b(gath))
+    return "fused_layer_kernel<%s, %s, %s, %s, false>" % (t, _b(radd), _b(vec), _b(gath))
 
 
-def dominant_kernel_roofline(sampler, reps=3):
+def _work(name, args, lib):
+    """-> (kernel symbol, algorithmic flops, algorithmic bytes) of one C-ABI call."""
+    if name == "pdr_fused_layer":
+        li = args[0]._obj
+        P, Cin, Cout, ldw, ldy = args[1], args[2], args[6], args[4], args[8]
+        plan = (_lib._c.c_int * 8)()
+        lib.pdr_fused_layer_plan(args[0], P, Cin, args[3], ldw, Cout, args[7], ldy, plan)
+        byt = 4.0 * P * Cout if args[7] else 0.0
+        for s in range(li.n_seg):
+            sg = li.seg[s]
+            if sg.gV:                                   # gathered source: table + per-query rows + index
+                byt += 4.0 * sg.C * (P // max(li.gK, 1)) + 4.0 * P
+            else:
+                byt += 4.0 * sg.C * (P // sg.row_div)
+        if li.rseg.ptr:
+            byt += 4.0 * P * Cin
+        return _layer_symbol(tuple(plan[:6])), 2.0 * P * Cin * Cout, byt
+    if name == "pdr_gather_add":
+        ldu, n_src, B, rpb, K, Cout, Y, ycols = args[1], args[2], args[12], args[13], args[14], args[15], args[16], args[21]
+        P = B * rpb
+        byt = 4.0 * (B * n_src * Cout + (P // K) * Cout + P) + (4.0 * P * (ycols if ycols > 0 else Cout) if Y else 0.0)
+        lpr = 16 if Cout <= 64 else (32 if Cout <= 128 else 64)
+        return "gather_add_kernel<%d>" % lpr, 2.0 * P * Cout, byt
+    if name == "pdr_attention_pool":
+        B, npoint, K, D = args[8], args[9], args[10], args[11]
+        P = B * npoint * K
+        return "attention_pool_*", 6.0 * P * D, 8.0 * P * D + 4.0 * B * npoint * D
+    return name.replace("pdr_", "") + " (C ABI)", 0.0, 0.0
+
+
+_TIMED = ("pdr_fused_layer", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
+          "pdr_furthest_point_sampling", "pdr_ball_query", "pdr_knn_points", "pdr_group_build", "pdr_knn_build",
+          "pdr_fused_layer_pool", "pdr_knn_weights", "pdr_pad_rows")
+
+
+def latest_traffic_file():
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+
+    def rnd(p):
+        m = re.search(r"r(\d+)_pmc_traffic", os.path.basename(p))
+        return int(m.group(1)) if m else -1
+    return max(files, key=rnd) if files else None
+
+
+def measured_traffic(symbol):
+    """(HBM bytes per launch, source file) of `symbol` from the newest committed PMC passes (FETCH_SIZE doubled
+    per the gfx950 correction + WRITE_SIZE, separate rocprofv3 runs of this bench)."""
+    path = latest_traffic_file()
+    if path is None:
+        raise LookupError("no profiles/r*_pmc_traffic.json")
+    key = symbol.replace(" ", "")
+    for k in json.load(open(path))["kernels"]:
+        if key in k["kernel"].replace(" ", ""):
+            return k["hbm_bytes_per_launch"], os.path.basename(path)
+    raise LookupError("%s has no entry for %s -- re-run tools/profile_round.sh" % (os.path.basename(path), symbol))
+
+
+def step_kernel_table(sampler, reps=3):
+    """HIP-event timing of every C-ABI launch of `reps` eager steps -> {symbol: [n, ms, flops, bytes]}."""
     lib = _lib.load()
     records = []
-    original = FN.run_layer
+    installed = []
+    for name in _TIMED:
+        if name not in _lib.SIGNATURES:
+            continue
+        fn = getattr(lib, name)
 
-    def timed(act, conv, *a, **k):
-        # the plain (no residual, no gathered source) 128 x 128 instantiation
-        hit = (lib.pdr_fused_layer_variant(act.rpb, conv.Cout) == DOMINANT_VARIANT and act.radd is None
-               and act.gidx is None)
-        if not hit:
-            return original(act, conv, *a, **k)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = original(act, conv, *a, **k)
-        e1.record()
-        seg_bytes = sum(4 * sg[2] * act.P // sg[4] for sg in act.segs)
-        records.append((e0, e1, 2.0 * act.P * conv.Cin * conv.Cout, seg_bytes + 4.0 * act.P * conv.Cout))
-        return out
-
-    FN.run_layer = timed
+        def make(name, fn):
+            def timed(*args):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args)
+                e1.record()
+                records.append((e0, e1) + _work(name, args, lib))
+                return rc
+            return timed
+        setattr(lib, name, make(name, fn))
+        installed.append((name, fn))
     try:
         with torch.no_grad():
             for _ in range(reps):
                 sampler._step()           # eager: the graph is not involved
         torch.cuda.synchronize()
     finally:
-        FN.run_layer = original
-    ms = sum(a.elapsed_time(b) for a, b, _, _ in records)
-    flops = sum(r[2] for r in records)
-    byts = sum(r[3] for r in records)
-    n = len(records)
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": measured_traffic(),
-            "kernel": DOMINANT_SYMBOL, "launches_per_step": n // reps,
-            "avg_launch_us": round(ms / n * 1e3, 2), "avg_gflop_per_launch": round(flops / n / 1e9, 3),
-            "algorithmic_GBps": round(byts / (ms * 1e-3) / 1e9, 1),
-            "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) roof; events on the launch stream, eager step x%d" % reps}
+        for name, fn in installed:
+            setattr(lib, name, fn)        # back to the CDLL's own (typed) function object
+    table = collections.OrderedDict()
+    for e0, e1, sym, fl, by in records:
+        row = table.setdefault(sym, [0, 0.0, 0.0, 0.0])
+        row[0] += 1
+        row[1] += e0.elapsed_time(e1)
+        row[2] += fl
+        row[3] += by
+    return table
+
+
+def _roof(flops, byt, ms, symbol):
+    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if "bf16x3" in symbol else FP32_MFMA_PEAK_TFLOPS
+    t_mfma = flops / (peak_tf * 1e12)
+    t_hbm = byt / (HBM_PEAK_GBS * 1e9)
+    if t_mfma >= t_hbm and flops > 0:
+        ach = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak_tf, 4)}
+    ach = byt / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4)}
+
+
+def dominant_kernel_roofline(sampler, reps=3):
+    table = step_kernel_table(sampler, reps)
+    ranked = sorted(table.items(), key=lambda kv: -kv[1][1])
+    sym, (n, ms, fl, by) = ranked[0]
+    out = _roof(fl, by, ms, sym)
+    try:
+        out["traffic"], out["traffic_source"] = measured_traffic(sym)
+    except (LookupError, OSError, KeyError, ValueError) as e:
+        out["traffic"], out["traffic_error"] = None, str(e)
+    total = sum(v[1] for v in table.values())
+    out.update({
+        "kernel": sym, "launches_per_step": n // reps, "avg_launch_us": round(ms / n * 1e3, 2),
+        "avg_gflop_per_launch": round(fl / n / 1e9, 3), "avg_algorithmic_MB_per_launch": round(by / n / 1e6, 2),
+        "share_of_step_kernel_time": round(ms / total, 4),
+        "note": "dominant = largest HIP-event time among the C-ABI launches of %d eager steps (events on the launch "
+                "stream include ~3 us of eager launch latency per call; rocprof durations are in profiles/)" % reps,
+        "next": [{"kernel": s, "share": round(v[1] / total, 4), **_roof(v[2], v[3], v[1], s)} for s, v in ranked[1:6]],
+    })
+    return out

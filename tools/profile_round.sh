@@ -1,0 +1,30 @@
+#!/bin/bash
+# One command -> every profile artefact of a round (run on the GPU box):
+#     bash tools/profile_round.sh r2            # writes gpurun_out/r2_*; copy the summaries into profiles/
+#   1. rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 3` (headline leg only)
+#   2. three SEPARATE --pmc passes of the same command at --steps 2 (kernel-trace only, as the guide prescribes):
+#      FETCH_SIZE, WRITE_SIZE (HBM traffic; FETCH_SIZE x2 gfx950 correction in the summary) and the SQ pass with
+#      SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES (MFMA utilisation of every kernel of the bench)
+#   3. tools/op_roofline.py: FPS / ball_query / kNN / Chamfer / EMD at the BASELINE sizes, HIP-event timed
+#   4. tools/profile_summary.py -> <tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json, <tag>_mfma_util.json,
+#      <tag>_roofline.json
+TAG=${1:-r2}
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --warmup 3 --no-cpu-baseline --no-roofline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o s -- $BENCH --steps 20 > $OUT/${TAG}_stats.log 2>&1
+tail -1 $OUT/${TAG}_stats.log | cut -c1-200
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc/$c -o p -- $BENCH --steps 2 > $OUT/${TAG}_pmc.$c.log 2>&1
+  tail -1 $OUT/${TAG}_pmc.$c.log | cut -c1-120
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+  --output-format csv -d $OUT/${TAG}_pmc/SQ -o p -- $BENCH --steps 2 > $OUT/${TAG}_pmc.SQ.log 2>&1
+tail -1 $OUT/${TAG}_pmc.SQ.log | cut -c1-120
+cd $REPO
+python tools/op_roofline.py > $OUT/${TAG}_op_roofline.json 2> $OUT/${TAG}_op_roofline.err
+python tools/profile_summary.py $OUT $TAG
+# raw counter dumps are large: keep only the summaries
+rm -rf $OUT/${TAG}_pmc $OUT/${TAG}_stats

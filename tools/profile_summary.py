@@ -1,0 +1,136 @@
+"""Summarise the passes of tools/profile_round.sh into the tracked round artefacts.
+
+    python tools/profile_summary.py <gpurun_out dir> <tag>
+
+<tag>_bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of bench.py (per kernel: calls, total, average ns)
+<tag>_pmc_traffic.json        HBM bytes per launch per kernel: FETCH_SIZE (units of 1024 B; on gfx950 it tallies the
+                              128-B requests of wide streaming reads at 64 B -> doubled, MI355X_MICROARCH.md, HBM
+                              section) + WRITE_SIZE (as reported), from two separate passes
+<tag>_mfma_util.json          per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs) -- the counter
+                              counts busy cycles of every SIMD's matrix pipe (checked: = #MFMA x 64 cycles for
+                              v_mfma_f32_32x32x2_f32) -- and SQ_BUSY_CU_CYCLES-relative occupancy figures
+<tag>_roofline.json           the table DESIGN.md quotes: per kernel of the step (>= 0.3 % of the time) average
+                              duration, launches per step, HBM GB/s vs 8 TB/s, MFMA utilisation vs the fp32 peak,
+                              which roof is nearer; plus the op-level rows of tools/op_roofline.py
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+CLOCK_HZ, SIMDS = 2.4e9, 1024
+HBM_PEAK = 8.0e12
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:]+(<[^(]*>)?)", name)
+    s = m.group(1) if m else name
+    return s[:100]
+
+
+def counters(path, wanted):
+    """{kernel: {counter: [sum, n]}, '_dur': [sum_ns, n]}"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            c = r["Counter_Name"]
+            if c in wanted:
+                k = short(r["Kernel_Name"])
+                acc[k][c][0] += float(r["Counter_Value"])
+                acc[k][c][1] += 1
+                if c == wanted[0]:
+                    acc[k]["_dur"][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                    acc[k]["_dur"][1] += 1
+    return acc
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    stats_src = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    stats = []
+    if stats_src:
+        shutil.copy(stats_src[0], os.path.join(out, tag + "_bench_kernel_stats.csv"))
+        stats = list(csv.DictReader(open(stats_src[0])))
+    pmc = os.path.join(out, tag + "_pmc")
+    fetch = counters(os.path.join(pmc, "FETCH_SIZE"), ["FETCH_SIZE"])
+    write = counters(os.path.join(pmc, "WRITE_SIZE"), ["WRITE_SIZE"])
+    sq = counters(os.path.join(pmc, "SQ"), ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES",
+                                            "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])
+    traffic = []
+    for k, v in fetch.items():
+        n = v["FETCH_SIZE"][1]
+        fb = 2.0 * 1024.0 * v["FETCH_SIZE"][0] / n
+        w = write.get(k, {}).get("WRITE_SIZE", [0.0, 0])
+        wb = 1024.0 * w[0] / max(w[1], 1)
+        traffic.append({"kernel": k, "launches": n, "fetch_bytes_per_launch": round(fb),
+                        "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb),
+                        "avg_us_under_pmc": round(v["_dur"][0] / max(v["_dur"][1], 1) / 1e3, 2)})
+    traffic.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
+    json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported; counter units of 1024 B; "
+                       "separate rocprofv3 --pmc passes of bench.py --steps 2",
+               "kernels": traffic[:60]}, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
+    mfma = []
+    for k, v in sq.items():
+        n = v["SQ_VALU_MFMA_BUSY_CYCLES"][1]
+        if n == 0:
+            continue
+        dur = v["_dur"][0] / max(v["_dur"][1], 1)           # ns
+        busy = v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / n
+        row = {"kernel": k, "launches": n, "avg_us_under_pmc": round(dur / 1e3, 2),
+               "mfma_busy_cycles_per_launch": round(busy),
+               "mfma_util": round(busy / (dur * 1e-9 * CLOCK_HZ * SIMDS), 4) if dur > 0 else None}
+        wc = v["SQ_WAVE_CYCLES"][0] / max(v["SQ_WAVE_CYCLES"][1], 1)
+        if wc > 0:
+            row["issue_stalled_frac_of_wave_cycles"] = round(v["SQ_WAIT_INST_ANY"][0] / max(v["SQ_WAIT_INST_ANY"][1], 1) / wc, 3)
+            row["active_frac_of_wave_cycles"] = round(v["SQ_ACTIVE_INST_ANY"][0] / max(v["SQ_ACTIVE_INST_ANY"][1], 1) / wc, 3)
+        mfma.append(row)
+    mfma.sort(key=lambda r: -r["mfma_busy_cycles_per_launch"] * r["launches"])
+    json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs); the fp32 "
+                       "MFMA peak (157.3 TF) corresponds to 1.0",
+               "kernels": mfma[:60]}, open(os.path.join(out, tag + "_mfma_util.json"), "w"), indent=1)
+    # ---- roofline table
+    tmap = {r["kernel"]: r for r in traffic}
+    mmap = {r["kernel"]: r for r in mfma}
+    rows, total = [], sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
+    nsteps = 20 + 3 + 2          # timed + warm-up + two first steps (bench.py: begin x2)
+    for r in stats:
+        share = float(r["TotalDurationNs"]) / total
+        if share < 0.003:
+            continue
+        k = short(r["Name"])
+        avg_us = float(r["AverageNs"]) / 1e3
+        row = {"kernel": k, "share_of_gpu_time": round(share, 4), "avg_us": round(avg_us, 2),
+               "launches_per_step": round(int(r["Calls"]) / nsteps, 1)}
+        t = tmap.get(k)
+        if t:
+            gbs = t["hbm_bytes_per_launch"] / (avg_us * 1e-6) / 1e9
+            row.update(hbm_MB_per_launch=round(t["hbm_bytes_per_launch"] / 1e6, 2), hbm_GBps=round(gbs, 1),
+                       hbm_frac_of_8TBps=round(gbs * 1e9 / HBM_PEAK, 3))
+        m = mmap.get(k)
+        if m and m["mfma_util"] is not None:
+            row["mfma_util"] = m["mfma_util"]
+        if "hbm_frac_of_8TBps" in row or "mfma_util" in row:
+            row["nearer_roof"] = "mfma" if row.get("mfma_util", 0) >= row.get("hbm_frac_of_8TBps", 0) else "hbm"
+        rows.append(row)
+    ops = None
+    try:
+        ops = json.load(open(os.path.join(out, tag + "_op_roofline.json")))
+    except (OSError, ValueError):
+        pass
+    json.dump({"note": "step kernels: rocprofv3 --kernel-trace --stats of bench.py (hipGraph replay) joined with the "
+                       "PMC passes; op rows: tools/op_roofline.py (HIP events, BASELINE sizes). Peaks: HBM 8 TB/s, "
+                       "fp32 MFMA = fp32 VALU = 157.3 TFLOP/s",
+               "step_kernels": rows, "ops": ops}, open(os.path.join(out, tag + "_roofline.json"), "w"), indent=1)
+    for r in rows[:14]:
+        print("%-64s %5.1f%% %8.1f us  hbm %5s  mfma %5s" % (r["kernel"][:64], 100 * r["share_of_gpu_time"], r["avg_us"],
+                                                            r.get("hbm_frac_of_8TBps", "-"), r.get("mfma_util", "-")))
+
+
+if __name__ == "__main__":
+    main()
