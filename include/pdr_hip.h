@@ -116,6 +116,18 @@ int pdr_three_interpolate_grad(const float *grad_out, const int *idx,
 int pdr_knn_points(const float *x, const float *y, int B, int n1, int n2, int K,
                    float *dists, int64_t *idx, float *nn, pdr_stream_t stream);
 
+/* Both nearest-neighbour searches of one Chamfer evaluation (chamfer_loss_new.py:149-150: knn_points(x, y, K=1)
+ * and knn_points(y, x, K=1)) in ONE launch: dist_xy / idx_xy (B,n1) = squared distance and index of the nearest
+ * y point of every x point, dist_yx / idx_yx (B,n2) the reverse; first minimum wins (in-tree cross-check
+ * chamfer3D.cu:26-129).  Bit-identical to two pdr_knn_points(K = 1) calls. */
+int pdr_chamfer_nn(const float *x, const float *y, int B, int n1, int n2, float *dist_xy,
+                   int64_t *idx_xy, float *dist_yx, int64_t *idx_yx, pdr_stream_t stream);
+/* pdr_knn_points for group_knn (pointnet2_utils.py:487-514) inside the fused network: same search, int32 indices
+ * and the normalised interpolation weights w = (1/(d2+1e-8)) / sum_k (1/(d2_k+1e-8)) of :500-503 (SQUARED
+ * distances, k ascending) in the same pass.  Requires K <= min(n2, 16). */
+int pdr_knn_group(const float *x, const float *y, int B, int n1, int n2, int K, float *dists, int *idx,
+                  float *weights, pdr_stream_t stream);
+
 /* Backward of pdr_knn_points w.r.t. both clouds (pytorch3d knn_points backward, norm 2;
  * makes chamfer_loss_new.py:149-167 / calc_cd :234-245 differentiable as train.py:518 needs;
  * K = 1 cross-check: chamfer3D.cu:155-195):
@@ -285,6 +297,18 @@ int pdr_gather_add(const float *U, int ldu, int n_src, const float *V, const flo
 /* out (B,m,C) = src (B,n,C)[idx (B,m)] */
 int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m, float *out,
                     pdr_stream_t stream);
+
+
+/* ---- reverse-step update ------------------------------------------------------
+ * The elementwise tail of one reverse step in one launch, step index and constants on the device:
+ *   mode 0 (util.py:246-250 `sampling`):       x <- (x - A[t] eps) / B[t] + C[t] z
+ *                                              A = (1-alpha)/sqrt(1-alpha_bar), B = sqrt(alpha), C = sigma (C[0] = 0)
+ *   mode 1 (util_fastdpmv2.py:186-204):        x <- x A[t] + (B[t] eps + C[t] z)
+ * x, z (npoints,3) dense (z may be NULL = 0); eps rows `ld_eps` floats apart; t_dev: int64 step index in device
+ * memory.  Same operations in the same order as the PyTorch expression (bit-identical). */
+int pdr_reverse_update(float *x, const float *eps, int ld_eps, const float *z, const float *tab_a,
+                       const float *tab_b, const float *tab_c, const long long *t_dev, long npoints,
+                       int mode, pdr_stream_t stream);
 
 #ifdef __cplusplus
 }

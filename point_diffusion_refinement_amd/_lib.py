@@ -32,6 +32,8 @@ SIGNATURES = {
     "pdr_three_interpolate": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_three_interpolate_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_knn_points": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pdr_chamfer_nn": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pdr_knn_group": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pdr_knn_points_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "pdr_emd_workspace_bytes": (_Z, [_I, _I, _I]),
     "pdr_matchcost_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -53,6 +55,7 @@ SIGNATURES = {
     "pdr_knn_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_attention_pool": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "pdr_reverse_update": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
     "pdr_gather_add": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
 }
 

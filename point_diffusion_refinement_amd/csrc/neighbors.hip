@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
                                                         int nc, int Kout,
                                                         float* __restrict__ dists,
                                                         IdxT* __restrict__ idx,
-                                                        float* __restrict__ nn) {
+                                                        float* __restrict__ nn,
+                                                        float* __restrict__ wgt = nullptr) {
   __shared__ float4 tile[kTile];
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -76,6 +77,18 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
   if (!active) return;
   float* od = dists + (static_cast<size_t>(b) * nq + j) * Kout;
   IdxT* oi = idx + (static_cast<size_t>(b) * nq + j) * Kout;
+  if (wgt) {
+    // group_knn's interpolation weights (pointnet2_utils.py:500-503): 1 / (d2 + 1e-8) normalised over the K
+    // neighbours (SQUARED distances), summed in ascending-k order like pdr_knn_build
+    float* ow = wgt + (static_cast<size_t>(b) * nq + j) * Kout;
+    float norm = 0.0f;
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+      if (t < Kout) norm += 1.0f / ((KNN_PAD && bi[t] < 0 ? 0.0f : bd[t]) + 1e-8f);
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+      if (t < Kout) ow[t] = (1.0f / ((KNN_PAD && bi[t] < 0 ? 0.0f : bd[t]) + 1e-8f)) / norm;
+  }
 #pragma unroll
   for (int t = 0; t < K; ++t) {
     if (t < Kout) {
@@ -89,6 +102,122 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
         on[1] = empty ? 0.0f : c[a * 3 + 1];
         on[2] = empty ? 0.0f : c[a * 3 + 2];
       }
+    }
+  }
+}
+
+// ---- K = 1 (Chamfer) ------------------------------------------------------------------------
+// chamfer_loss_new.py:149-167 asks knn_points(K=1) twice (x -> y and y -> x); 8.39 M pair evaluations per
+// 2048^2 cloud pair, so the kernel is bound by VALU ISSUE SLOTS per pair, not by memory.  The generic kernel above
+// spends ~9 slots per pair (6 distance + compare + 2 selects) plus one LDS read.  Here:
+//   * a thread owns 2 QP queries held as QP float PAIRS: the distance expression runs on packed fp32
+//     (v_pk_add / v_pk_mul / v_pk_fma: two queries per instruction, each lane IEEE-exact, same ACC3 expression
+//     tree as the generic kernel -> bit-identical distances);
+//   * every LDS point (one ds_read, broadcast) serves all 2 QP queries;
+//   * no per-pair index bookkeeping: per chunk of CH points only the running minimum (v_min / v_min3) is kept,
+//     and once per chunk `chunk_min < best` (STRICT) records the chunk; when the scan is over the ONE recorded
+//     chunk of each query is rescanned in ascending order with strict `<`, which returns the first (lowest-index)
+//     point attaining the minimum = "first minimum wins" (chamfer3D.cu:26-129, pdr_hip.h knn contract).
+// ~4 issue slots per pair.  blockIdx.z selects the direction so both searches of a Chamfer evaluation are one launch.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int QP, typename IdxT>
+__global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                  int na, int nb, float* __restrict__ da,
+                                                  IdxT* __restrict__ ia, float* __restrict__ db,
+                                                  IdxT* __restrict__ ib) {
+  constexpr int CH = 8;
+  constexpr int NQ = 2 * QP;                       // queries per thread
+  __shared__ float4 tile[kTile];
+  const int dir = blockIdx.z;
+  const float* queries = dir ? xb : xa;
+  const float* cloud = dir ? xa : xb;
+  const int nq = dir ? nb : na, nc = dir ? na : nb;
+  float* dists = dir ? db : da;
+  IdxT* idx = dir ? ib : ia;
+  if (static_cast<int>(blockIdx.x) * 256 * NQ >= nq) return;   // uniform: the grid covers max(na, nb)
+  const int b = blockIdx.y;
+  const float* c = cloud + static_cast<size_t>(b) * nc * 3;
+  // thread t owns queries q0 + t + 256 i (coalesced loads / stores); out-of-range slots shadow the last query
+  const int q0 = blockIdx.x * 256 * NQ + threadIdx.x;
+  f32x2 qx[QP], qy[QP], qz[QP], best[QP];
+  int bchunk[NQ];
+#pragma unroll
+  for (int p = 0; p < QP; ++p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = min(q0 + 256 * (2 * p + h), nq - 1);
+      const float* q = queries + (static_cast<size_t>(b) * nq + j) * 3;
+      qx[p][h] = q[0];
+      qy[p][h] = q[1];
+      qz[p][h] = q[2];
+      bchunk[2 * p + h] = 0;
+    }
+    best[p] = f32x2{__builtin_inff(), __builtin_inff()};
+  }
+  for (int k0 = 0; k0 < nc; k0 += kTile) {
+    const int kn = (nc - k0) < kTile ? (nc - k0) : kTile;
+    const int kpad = (kn + CH - 1) / CH * CH;
+    __syncthreads();
+    for (int t = threadIdx.x; t < kpad; t += 256) {
+      const float* s = c + static_cast<size_t>(k0 + min(t, kn - 1)) * 3;
+      // slots beyond the cloud: +inf coordinates -> distance +inf, never below any minimum
+      tile[t] = t < kn ? make_float4(s[0], s[1], s[2], 0.0f)
+                       : make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f);
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < kpad; t0 += CH) {
+      f32x2 cm[QP];
+#pragma unroll
+      for (int p = 0; p < QP; ++p) cm[p] = f32x2{__builtin_inff(), __builtin_inff()};
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const float4 pt = tile[t0 + u];
+#pragma unroll
+        for (int p = 0; p < QP; ++p) {
+          const f32x2 dx = qx[p] - pt.x, dy = qy[p] - pt.y, dz = qz[p] - pt.z;
+          f32x2 d = dx * dx;                                   // PDR_ACC3 on both lanes of the pair
+          d = __builtin_elementwise_fma(dy, dy, d);
+          d = __builtin_elementwise_fma(dz, dz, d);
+          cm[p] = __builtin_elementwise_min(cm[p], d);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < QP; ++p) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool up = cm[p][h] < best[p][h];               // strict: the EARLIEST chunk holding the minimum
+          best[p][h] = up ? cm[p][h] : best[p][h];
+          bchunk[2 * p + h] = up ? k0 + t0 : bchunk[2 * p + h];
+        }
+      }
+    }
+  }
+  // index recovery: rescan each query's recorded chunk (CH points from global memory, ascending, strict <)
+#pragma unroll
+  for (int p = 0; p < QP; ++p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = q0 + 256 * (2 * p + h);
+      if (j >= nq) continue;
+      const float x0 = qx[p][h], y0 = qy[p][h], z0 = qz[p][h];
+      float lb = __builtin_inff();
+      int li = -1;
+      const int cs = bchunk[2 * p + h];
+      for (int u = 0; u < CH; ++u) {
+        const int k = cs + u;
+        if (k < nc) {
+          const float dx = x0 - c[k * 3 + 0], dy = y0 - c[k * 3 + 1], dz = z0 - c[k * 3 + 2];
+          const float d = PDR_ACC3(dx, dy, dz);
+          if (d < lb) {
+            lb = d;
+            li = k;
+          }
+        }
+      }
+      const size_t o = static_cast<size_t>(b) * nq + j;
+      dists[o] = li < 0 ? 0.0f : lb;                           // empty cloud: pytorch3d padding (0, -1)
+      idx[o] = static_cast<IdxT>(li);
     }
   }
 }
@@ -123,11 +252,52 @@ extern "C" int pdr_knn_points(const float* x, const float* y, int B, int n1, int
   if (B == 0 || n1 == 0) return PDR_OK;
   if (!x || !dists || !idx || (n2 > 0 && !y)) return PDR_EINVAL;
   hipStream_t s = pdr::as_stream(stream);
+  if (K == 1 && !nn && n2 > 0) {
+    // dedicated packed-math kernel (one direction of pdr_chamfer_nn); bit-identical results
+    hipLaunchKernelGGL((nn1_kernel<2, int64_t>), dim3((n1 + 1023) / 1024, B, 1), dim3(256), 0, s, x, y, n1, n2,
+                       dists, idx, static_cast<float*>(nullptr), static_cast<int64_t*>(nullptr));
+    return pdr::check_launch();
+  }
   if (K == 1) return launch_knn<1>(x, y, B, n1, n2, K, dists, idx, nn, s);
   if (K <= 4) return launch_knn<4>(x, y, B, n1, n2, K, dists, idx, nn, s);
   if (K <= 8) return launch_knn<8>(x, y, B, n1, n2, K, dists, idx, nn, s);
   if (K <= 16) return launch_knn<16>(x, y, B, n1, n2, K, dists, idx, nn, s);
   return launch_knn<32>(x, y, B, n1, n2, K, dists, idx, nn, s);
+}
+
+// Both nearest-neighbour searches of a Chamfer evaluation (chamfer_loss_new.py:149-150, 166-167) in ONE launch:
+//   dist_xy[b,i] = min_j |x_i - y_j|^2, idx_xy = argmin (first minimum wins);  dist_yx / idx_yx the reverse.
+// Identical to two pdr_knn_points(K = 1) calls, bit for bit.
+extern "C" int pdr_chamfer_nn(const float* x, const float* y, int B, int n1, int n2, float* dist_xy,
+                              int64_t* idx_xy, float* dist_yx, int64_t* idx_yx, pdr_stream_t stream) {
+  if (B < 0 || n1 <= 0 || n2 <= 0) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  if (!x || !y || !dist_xy || !idx_xy || !dist_yx || !idx_yx) return PDR_EINVAL;
+  const int nmax = n1 > n2 ? n1 : n2;
+  hipLaunchKernelGGL((nn1_kernel<2, int64_t>), dim3((nmax + 1023) / 1024, B, 2), dim3(256), 0,
+                     pdr::as_stream(stream), x, y, n1, n2, dist_xy, idx_xy, dist_yx, idx_yx);
+  return pdr::check_launch();
+}
+
+// knn_points for the fused network's feature propagation (group_knn, pointnet2_utils.py:487-514): the same search
+// as pdr_knn_points with int32 indices (what pdr_gather_add reads) and the normalised inverse-squared-distance
+// interpolation weights of :500-503 in the same pass.  Requires K <= n2 (no padding slots).
+extern "C" int pdr_knn_group(const float* x, const float* y, int B, int n1, int n2, int K, float* dists,
+                             int* idx, float* weights, pdr_stream_t stream) {
+  if (B < 0 || n1 < 0 || n2 <= 0 || K <= 0 || K > n2) return PDR_EINVAL;
+  if (K > 16) return PDR_EUNSUPPORTED;
+  if (B == 0 || n1 == 0) return PDR_OK;
+  if (!x || !y || !dists || !idx || !weights) return PDR_EINVAL;
+  hipStream_t s = pdr::as_stream(stream);
+  const dim3 grid((n1 + 255) / 256, B);
+#define PDR_KG(KK)                                                                                      \
+  hipLaunchKernelGGL((nn_search_kernel<KK, kAcc3, int, false>), grid, dim3(256), 0, s, x, y, n1, n2, K,  \
+                     dists, idx, static_cast<float*>(nullptr), weights)
+  if (K <= 4) PDR_KG(4);
+  else if (K <= 8) PDR_KG(8);
+  else PDR_KG(16);
+#undef PDR_KG
+  return pdr::check_launch();
 }
 
 // ---- kNN backward (pytorch3d knn_points backward, norm 2; cf. chamfer3D.cu:155-195 for K = 1) ----

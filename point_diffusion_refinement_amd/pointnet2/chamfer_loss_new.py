@@ -2,9 +2,12 @@
 (chamfer_distance :67-217, fscore :219-232, calc_cd :234-245, Chamfer_F1 :247-256).
 
 The two nearest-neighbour searches (pytorch3d knn_points K=1 in the reference,
-:149-150) run on libpdr_hip.so.  Built path = dense clouds of equal length per
-batch (what completion_eval.py feeds); ragged `x_lengths`/`y_lengths` and
-pytorch3d `Pointclouds` inputs are rejected with NotImplementedError.
+:149-150) run on libpdr_hip.so: ONE launch for both directions (pdr_chamfer_nn) on the
+hot path = dense clouds of equal length per batch without gradient (what
+completion_eval.py feeds); two differentiable knn_points calls when a gradient is
+needed (train.py:518).  Ragged `x_lengths` / `y_lengths` take a slow per-sample path
+over the same kernels (reference :121-128, 152-155 semantics: padded points are not
+candidates and contribute 0); pytorch3d `Pointclouds` objects are rejected.
 All distances are SQUARED; cd_p takes the square root per point before the mean;
 the F-score threshold is applied to squared distances.
 """
@@ -35,17 +38,38 @@ def _dense(points, lengths, normals, name):
     if lengths is not None:
         if lengths.ndim != 1 or lengths.shape[0] != points.shape[0]:
             raise ValueError("Expected lengths to be of shape (N,)")
-        if bool((lengths != points.shape[1]).any()):
-            raise NotImplementedError("%s_lengths: ragged clouds are not on the built path" % name)
     if normals is not None and normals.ndim != 3:
         raise ValueError("Expected normals to be of shape (N, P, 3")
-    full = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
-    return points, full, normals
+    if lengths is None:
+        lengths = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
+    return points, lengths, normals
 
 
 def _nearest(a, b):
     d, i, _ = _ext.knn_points(a.contiguous(), b.contiguous(), 1)
     return d[..., 0], i[..., 0]
+
+
+def _nearest_both(x, y):
+    """(cham_x, idx_x, cham_y, idx_y) of dense clouds: one launch without autograd, two differentiable searches
+    otherwise."""
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        return _nearest(x, y) + _nearest(y, x)
+    return _ext.chamfer_nn(x.contiguous(), y.contiguous())
+
+
+def _nearest_ragged(a, la, b, lb):
+    """Slow path for heterogeneous lengths: sample n searches a[n, :la[n]] in b[n, :lb[n]]; padded queries get
+    distance 0 / index 0 (what the reference's masking leaves, :152-155)."""
+    d = a.new_zeros(a.shape[:2])
+    i = torch.zeros(a.shape[:2], dtype=torch.int64, device=a.device)
+    for n in range(a.shape[0]):
+        na, nb = int(la[n]), int(lb[n])
+        if na == 0 or nb == 0:
+            continue
+        dn, jn = _nearest(a[n:n + 1, :na], b[n:n + 1, :nb])
+        d[n, :na], i[n, :na] = dn[0], jn[0]
+    return d, i
 
 
 def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,
@@ -70,8 +94,17 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
                 return z.sum() * 0.0, z.sum() * 0.0
             return z * 0.0, z * 0.0
 
-    cham_x, idx_x = _nearest(x, y)
-    cham_y, idx_y = _nearest(y, x)
+    P2 = y.shape[1]
+    ragged = bool((x_lengths != P1).any()) or bool((y_lengths != P2).any())
+    if ragged:
+        if bool((x_lengths > P1).any()) or bool((y_lengths > P2).any()):
+            raise ValueError("lengths exceed the padded size")
+        cham_x, idx_x = _nearest_ragged(x, x_lengths, y, y_lengths)
+        cham_y, idx_y = _nearest_ragged(y, y_lengths, x, x_lengths)
+        x_mask = torch.arange(P1, device=x.device)[None] >= x_lengths[:, None]
+        y_mask = torch.arange(P2, device=y.device)[None] >= y_lengths[:, None]
+    else:
+        cham_x, idx_x, cham_y, idx_y = _nearest_both(x, y)
     norm_x = norm_y = x.new_zeros(())
     if weights is not None:
         cham_x = cham_x * weights.view(N, 1)
@@ -81,6 +114,9 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
         near_y = x_normals.gather(1, idx_y.unsqueeze(-1).expand(-1, -1, x_normals.shape[2]))
         norm_x = 1 - torch.abs(F.cosine_similarity(x_normals, near_x, dim=2, eps=1e-6))
         norm_y = 1 - torch.abs(F.cosine_similarity(y_normals, near_y, dim=2, eps=1e-6))
+        if ragged:
+            norm_x = norm_x.masked_fill(x_mask, 0.0)
+            norm_y = norm_y.masked_fill(y_mask, 0.0)
         if weights is not None:
             norm_x = norm_x * weights.view(N, 1)
             norm_y = norm_y * weights.view(N, 1)

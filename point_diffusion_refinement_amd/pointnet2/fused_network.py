@@ -198,16 +198,20 @@ class Conv:
         self.widths = [w.shape[0] for w in ws]
 
 
+def _ldy(Cout):
+    # rows of wide, odd-width outputs (105, 140, 297 ... = [first | res | key] GEMMs) start on
+    # 128-byte boundaries: pad the leading dimension, consumers address columns through `ld`
+    # (narrow outputs: a multiple of 4 floats, so that consumers can stage them with 16-B loads)
+    return _pad4(Cout) if (Cout <= 64 or Cout % 32 == 0) else (Cout + 31) // 32 * 32
+
+
 def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
     """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch).
     extra_rows: zero rows appended to Y (the zero row of a gathered table); out = (tensor, col0): write into
     columns [col0, col0 + ldy') of an existing (P, ld) tensor instead of allocating."""
     lib = _lib.load()
     assert act.C == conv.Cin, (act.C, conv.Cin)
-    # rows of wide, odd-width outputs (105, 140, 297 ... = [first | res | key] GEMMs) start on
-    # 128-byte boundaries: pad the leading dimension, consumers address columns through `ld`
-    # (narrow outputs: a multiple of 4 floats, so that consumers can stage them with 16-B loads)
-    ldy = _pad4(conv.Cout) if (conv.Cout <= 64 or conv.Cout % 32 == 0) else (conv.Cout + 31) // 32 * 32
+    ldy = _ldy(conv.Cout)
     if out is not None:
         Y, ycol0 = out
         y_ptr, ldy = _ptr(Y, ycol0), Y.shape[1]
@@ -485,6 +489,7 @@ class SplitFirstConv:
     def __init__(self, first, Cs, kind, with_abs=True, with_centre=True):
         Wt, bias, Cout, dev = first.Wt, first.bias, first.Cout, first.Wt.device
         self.Cout, self.ld = Cout, first.ldw
+        self._tables = {}
         zero3 = torch.zeros((3, first.ldw), device=dev)
         zb = torch.zeros_like(bias)
         pad_bias = torch.zeros(first.ldw, device=dev)
@@ -513,8 +518,14 @@ class SplitFirstConv:
         feature-transfer blocks read the retained condition features) compute it once per batch."""
         B, n, Cs = src_feats_cl.shape
         u_in = Act([(xyz4(src_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
-        U, _, _ = run_layer(u_in, self.U, extra_rows=1)
-        return U
+        # the table lives in a buffer owned by this block (one per shape), zeroed ONCE: the GEMM rewrites rows
+        # [0, B n) every call and nothing ever writes the trailing zero row, so no fill launch per step
+        key = (B * n + 1, _ldy(self.U.Cout))
+        buf = self._tables.get(key)
+        if buf is None:
+            buf = self._tables[key] = torch.zeros(key, dtype=torch.float32, device=src_xyz.device)
+        run_layer(u_in, self.U, out=(buf, 0))
+        return buf
 
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
                  virtual=False, res=None, U=None):
@@ -610,7 +621,9 @@ class FusedGroupedBlock:
         if not USE_SPLIT_FIRST:
             return
         U = self._make_split(src_feats_cl.shape[2]).source_table(src_feats_cl, src_xyz)
-        if self.static_U is not None and self.static_U.shape == U.shape:
+        if self.static_U is U:
+            pass                      # the block's own table buffer (rewritten in place by source_table)
+        elif self.static_U is not None and self.static_U.shape == U.shape:
             self.static_U.copy_(U)
         else:
             self.static_U = U
@@ -665,20 +678,20 @@ class FusedKnnFP:
         B, n, _ = unknown.shape
         n2, C = known.shape[1], known_feats_cl.shape[2]
         K = self.K
-        d2, idx = knn if knn is not None else _ext.knn_points(unknown, known, K)[:2]
+        # squared distances, int32 neighbour indices and group_knn's normalised 1/(d2+1e-8) weights from ONE
+        # native call (normally issued by the geometry prepass on the side stream)
+        d2, idx, wgt = knn if knn is not None else _ext.knn_group(unknown, known, K)
         if USE_SPLIT_FIRST:
             if self.split is None:
                 self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
-            # inverse-(squared-)distance weights exactly as group_knn: 1/(d2+1e-8), normalised over K
-            recip = 1.0 / (d2 + 1e-8)
-            wgt = recip / torch.sum(recip, dim=2, keepdim=True)
-            Y1, part1, tpb1 = self.split(known_feats_cl, known, unknown, idx.int(), None, K, self.mlp1.extra_col0,
-                                         s1=d2.contiguous(), s2=wgt.contiguous())
+            Y1, part1, tpb1 = self.split(known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0,
+                                         s1=d2, s2=wgt)
             h, Y1, part1, tpb1 = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
         else:
             G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
+            idx64 = idx.long()
             _lib.check(lib.pdr_knn_build(known_feats_cl.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
-                                         idx.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
+                                         idx64.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
                                          _stream()), "knn_build")
             h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
         interp = self.att(unknown_feats_cl.reshape(B * n, -1), h, Y1, part1, tpb1, self.mlp1.extra_col0, None, B, n,
@@ -736,6 +749,7 @@ class FusedCloudConditionNet:
         self.enc_cl = self.dec_cl = None
         self._synced = False
         self._side = None
+        self.return_strided_eps = False
 
     def _side_stream(self):
         if self._side is None:
@@ -823,8 +837,9 @@ class FusedCloudConditionNet:
         B, N, _ = pointcloud.shape
         _XYZ4.clear()
         xyz = pointcloud[:, :, 0:3].contiguous()
-        feat0 = torch.cat([pointcloud[:, :, 3:], xyz / net.scale_factor], dim=2).contiguous() \
-            if pointcloud.shape[2] > 3 else (xyz / net.scale_factor)
+        # scale_factor == 1 (checked at construction): xyz / 1 is xyz, bit for bit -- no division kernel, and the
+        # 16-byte padded copy of the coordinates serves as the level-0 feature rows too
+        feat0 = torch.cat([pointcloud[:, :, 3:], xyz], dim=2).contiguous() if pointcloud.shape[2] > 3 else xyz
         if not self._synced:
             self.sync_condition()
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
@@ -869,8 +884,7 @@ class FusedCloudConditionNet:
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
             for i in range(-1, -(len(self.fp) + 1), -1):
-                d2, idx, _ = _ext.knn_points(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
-                knn[i] = (d2, idx)
+                knn[i] = _ext.knn_group(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
             ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
             ev_knn.record(side)
 
@@ -929,7 +943,10 @@ class FusedCloudConditionNet:
         s, t = self.head_norm.fold([(part, 0, self.head1.Cout, tpb, 1.0)], B, self.head1.Cout, N)
         out, _, _ = run_layer(Act([(Y, 0, self.head1.Cout, Y.shape[1], 1)], B * N, B, N, scale=s, shift=t,
                                   post_relu=True), self.head2)
-        return out[:, :self.head2.Cout].reshape(B, N, -1)
+        eps = out.view(B, N, out.shape[1])[:, :, :self.head2.Cout]
+        # (B, N, Cout) view over the layer's 4-float rows; samplers consume it in place (pdr_reverse_update reads a
+        # leading dimension), everybody else gets the dense tensor the module returns
+        return eps if self.return_strided_eps else eps.contiguous()
 
     __call__ = forward
 

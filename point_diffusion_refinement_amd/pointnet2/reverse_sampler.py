@@ -40,6 +40,8 @@ class GraphedReverseSampler:
         self.sigma = sig.to(self.device)
         self._graph = None
         self._key = None
+        if hasattr(net, "return_strided_eps"):
+            net.return_strided_eps = True              # fused network: hand over its 4-float output rows as a view
 
     # ------------------------------------------------------------------ one step
     NOISE_AT_LAST_STEP = False     # util.sampling draws no noise at t = 0
@@ -48,17 +50,41 @@ class GraphedReverseSampler:
         """Network time input of the step whose device counter is `t` ((1,) int64)."""
         return t.to(torch.float32)
 
+    UPDATE_MODE = 0                # pdr_reverse_update: 0 = DDPM ancestral step, 1 = FastDPM / DDIM-style step
+
+    def _tables(self):
+        return self.c_eps, self.sqrt_alpha, self.sigma
+
     def _update(self, x, eps, t, z):
+        """Reference expression (util.py:246-250) in PyTorch ops -- the host-logic / CPU form; on the GPU the same
+        operations run as ONE native launch (`_update_native`, bit-identical)."""
         # index_select keeps the lookup on the device (tensor[t] with a 0-d index would call .item())
-        c_eps, sqrt_a, sigma = (tab.index_select(0, t) for tab in (self.c_eps, self.sqrt_alpha, self.sigma))
+        c_eps, sqrt_a, sigma = (tab.index_select(0, t) for tab in self._tables())
         return (x - c_eps * eps) / sqrt_a + sigma * z
+
+    def _update_native(self, eps, z):
+        """x <- update(x, eps, z) in place through pdr_reverse_update: step index and constants stay on the device;
+        eps may be the strided (.., 4)-row view the fused network's last layer writes."""
+        from .. import _lib
+        x = self._x
+        B, N, _ = x.shape
+        if not (eps.stride(2) == 1 and eps.stride(0) == N * eps.stride(1)):
+            eps = eps.contiguous()
+        a, b, c = self._tables()
+        _lib.check(_lib.load().pdr_reverse_update(x.data_ptr(), eps.data_ptr(), eps.stride(1), z.data_ptr(),
+                                                  a.data_ptr(), b.data_ptr(), c.data_ptr(), self._t.data_ptr(), B * N,
+                                                  self.UPDATE_MODE, torch.cuda.current_stream().cuda_stream),
+                   "reverse_update")
 
     def _step(self):
         t = self._t                                   # (1,) int64 on device, counts down to 0
         ts = self._timestep(t).expand(self._x.shape[0])
         eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
         z = torch.randn_like(self._x) if self.noise == 'device' else self._z
-        self._x.copy_(self._update(self._x, eps, t, z))
+        if self._x.is_cuda and self._x.dtype == torch.float32 and self._x.shape[2] == 3:
+            self._update_native(eps, z)
+        else:
+            self._x.copy_(self._update(self._x, eps, t, z))
         self._t.sub_(1)
 
     def _prepare(self, size, condition, label):
@@ -220,10 +246,15 @@ class GraphedFastSampler(GraphedReverseSampler):
         self.f_scale, self.f_c, self.f_sigma, self.f_tau = rev(scale), rev(c), rev(sig), rev(tau)
         self.T = n
 
+    UPDATE_MODE = 1
+
     def _timestep(self, t):
         return self.f_tau.index_select(0, t)
 
+    def _tables(self):
+        return self.f_scale, self.f_c, self.f_sigma
+
     def _update(self, x, eps, t, z):
-        scale, c, sigma = (tab.index_select(0, t) for tab in (self.f_scale, self.f_c, self.f_sigma))
+        scale, c, sigma = (tab.index_select(0, t) for tab in self._tables())
         x = x * scale
         return x + (c * eps + sigma * z)

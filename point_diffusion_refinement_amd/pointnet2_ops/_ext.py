@@ -179,6 +179,44 @@ def _knn_forward(p1, p2, K, return_nn):
     return dists, idx, nn
 
 
+def chamfer_nn(x, y):
+    """Both K = 1 searches of a Chamfer evaluation in one launch:
+    (B,n1,3), (B,n2,3) -> (dist_xy (B,n1), idx_xy (B,n1) i64, dist_yx (B,n2), idx_yx (B,n2) i64); not differentiable
+    (chamfer_distance uses knn_points when a gradient is needed)."""
+    _req(x, "x", torch.float32)
+    _req(y, "y", torch.float32)
+    _same_device(x, y)
+    if x.shape[2] != 3 or y.shape[2] != 3 or x.shape[0] != y.shape[0]:
+        raise RuntimeError("chamfer_nn: (B,n,3) clouds with equal batch size")
+    B, n1, _ = x.shape
+    n2 = y.shape[1]
+    dx = torch.empty((B, n1), dtype=torch.float32, device=x.device)
+    dy = torch.empty((B, n2), dtype=torch.float32, device=x.device)
+    ix = torch.empty((B, n1), dtype=torch.int64, device=x.device)
+    iy = torch.empty((B, n2), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().pdr_chamfer_nn(x.data_ptr(), y.data_ptr(), B, n1, n2, dx.data_ptr(), ix.data_ptr(),
+                                              dy.data_ptr(), iy.data_ptr(), _stream()), "chamfer_nn")
+    return dx, ix, dy, iy
+
+
+def knn_group(x, y, K):
+    """knn_points for group_knn in the fused network: (dists (B,n1,K) f32, idx (B,n1,K) i32, weights (B,n1,K) f32)
+    with weights = normalised 1 / (d2 + 1e-8) (pointnet2_utils.py:500-503)."""
+    _req(x, "x", torch.float32)
+    _req(y, "y", torch.float32)
+    _same_device(x, y)
+    B, n1, _ = x.shape
+    n2 = y.shape[1]
+    d = torch.empty((B, n1, K), dtype=torch.float32, device=x.device)
+    w = torch.empty((B, n1, K), dtype=torch.float32, device=x.device)
+    i = torch.empty((B, n1, K), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().pdr_knn_group(x.data_ptr(), y.data_ptr(), B, n1, n2, int(K), d.data_ptr(),
+                                             i.data_ptr(), w.data_ptr(), _stream()), "knn_group")
+    return d, i, w
+
+
 class _KnnDists(torch.autograd.Function):
     """Differentiable squared distances of knn_points (pytorch3d `_knn_points` backward, norm 2)."""
 

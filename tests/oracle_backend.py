@@ -33,6 +33,12 @@ def _knn_points(p1, p2, K, return_nn=False):
     return d, i, nn
 
 
+def _chamfer_nn(x, y):
+    dx, ix = O.knn(_n(x), _n(y), 1)
+    dy, iy = O.knn(_n(y), _n(x), 1)
+    return _t(dx[..., 0]), _t(ix[..., 0]), _t(dy[..., 0]), _t(iy[..., 0])
+
+
 ORACLE_EXT = {
     "furthest_point_sampling": lambda pts, n: _t(O.furthest_point_sampling(_n(pts), n)),
     "gather_points": lambda pts, idx: _t(O.gather_points(_n(pts), _n(idx))),
@@ -44,6 +50,7 @@ ORACLE_EXT = {
     "three_interpolate": lambda p, i, w: _t(O.three_interpolate(_n(p), _n(i), _n(w))),
     "three_interpolate_grad": lambda g, i, w, m: _t(O.three_interpolate_grad(_n(g), _n(i), _n(w), m)),
     "knn_points": _knn_points,
+    "chamfer_nn": _chamfer_nn,
 }
 
 

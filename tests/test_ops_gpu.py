@@ -205,6 +205,45 @@ def test_group_knn_layout(cuda):
     np.testing.assert_array_equal(out[:, 13:16], np.broadcast_to(x.transpose(0, 2, 1)[..., None], (2, 3, 64, 8)))
 
 
+@pytest.mark.parametrize("B,n1,n2", [(1, 1, 1), (2, 100, 200), (3, 2048, 2048), (2, 1025, 1031), (1, 5000, 3), (2, 7, 4100),
+                                     (1, 16384, 16384)])
+def test_chamfer_nn_both_directions_bit_equal_to_knn(cuda, B, n1, n2):
+    """pdr_chamfer_nn (packed-math K = 1 kernel, both directions in one launch) == oracle knn(K=1) bit for bit:
+    distances AND first-minimum-wins indices, with exact ties (integer lattice) and exact zero distances."""
+    rr = rng(n1 * 7 + n2)
+    x = rr.uniform(-1, 1, (B, n1, 3)).astype(np.float32)
+    y = rr.uniform(-1, 1, (B, n2, 3)).astype(np.float32)
+    # many exact ties: snap half of both clouds to a coarse lattice; exact zeros: copy some points across
+    x[:, ::2] = np.round(x[:, ::2] * 4) / 4
+    y[:, ::2] = np.round(y[:, ::2] * 4) / 4
+    k = min(n1, n2) // 3
+    if k:
+        x[:, 1:1 + k] = y[:, :k]
+    dx, ix, dy, iy = (host(t) for t in _ext.chamfer_nn(dev(x, cuda), dev(y, cuda)))
+    od, oi = O.knn(x, y, 1)
+    rd, ri = O.knn(y, x, 1)
+    assert np.array_equal(ix, oi[..., 0]) and np.array_equal(dx, od[..., 0])
+    assert np.array_equal(iy, ri[..., 0]) and np.array_equal(dy, rd[..., 0])
+    # the K = 1 route of knn_points is the same kernel (single direction)
+    d1, i1, _ = _ext.knn_points(dev(x, cuda), dev(y, cuda), 1)
+    assert np.array_equal(host(i1)[..., 0], ix) and np.array_equal(host(d1)[..., 0], dx)
+
+
+@pytest.mark.parametrize("B,n1,n2,K", [(2, 64, 16, 8), (2, 2048, 1024, 8), (1, 300, 40, 3), (2, 1024, 256, 16)])
+def test_knn_group_indices_and_weights(cuda, B, n1, n2, K):
+    """pdr_knn_group = knn_points (index-exact, int32) + group_knn's normalised 1/(d2+1e-8) weights."""
+    rr = rng(n1 + n2 + K)
+    x = rr.uniform(-1, 1, (B, n1, 3)).astype(np.float32)
+    y = rr.uniform(-1, 1, (B, n2, 3)).astype(np.float32)
+    x[:, ::5] = y[:, : len(x[0, ::5])] if n2 >= len(x[0, ::5]) else x[:, ::5]       # exact zero distances
+    d, i, w = _ext.knn_group(dev(x, cuda), dev(y, cuda), K)
+    od, oi = O.knn(x, y, K)
+    assert i.dtype == torch.int32
+    assert np.array_equal(host(i), oi.astype(np.int32)) and np.array_equal(host(d), od)
+    recip = 1.0 / (od.astype(np.float64) + 1e-8)
+    np.testing.assert_allclose(host(w), recip / recip.sum(-1, keepdims=True), rtol=2e-6)
+
+
 # -------------------------------------------------------------- Chamfer
 def test_chamfer_unit_test_protocol(cuda):
     """Same protocol as the reference's ChamferDistancePytorch/unit_test.py:22-33."""
@@ -309,3 +348,27 @@ def test_ops_honour_the_current_stream_and_graph_capture(cuda):
     assert torch.equal(idx, ref)
     oi, oc = O.ball_query(host(x[:, :64]), host(x), 0.2, 16)
     assert np.array_equal(host(bi), oi) and np.array_equal(host(bc), oc)
+
+
+# ------------------------------------------------------------ reverse-step update
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reverse_update_is_bit_identical_to_the_torch_expression(cuda, mode):
+    """pdr_reverse_update == the reference's elementwise expressions evaluated op by op in PyTorch
+    (util.py:246-250 / util_fastdpmv2.py:186-204), step index read from device memory, strided eps rows."""
+    from point_diffusion_refinement_amd import _lib
+    g = torch.Generator().manual_seed(5 + mode)
+    B, N, T = 3, 1000, 50
+    x = torch.randn(B, N, 3, generator=g).to(cuda)
+    eps4 = torch.randn(B, N, 4, generator=g).to(cuda)
+    eps = eps4[:, :, :3]                                                   # leading dimension 4
+    z = torch.randn(B, N, 3, generator=g).to(cuda)
+    a, b, c = (torch.rand(T, generator=g).to(cuda) + 0.5 for _ in range(3))
+    for step in (T - 1, 7, 0):
+        t = torch.tensor([step], dtype=torch.int64, device=cuda)
+        A, Bc, C = a[step], b[step], c[step]
+        want = (x - A * eps) / Bc + C * z if mode == 0 else (x * A) + (Bc * eps + C * z)
+        got = x.clone()
+        _lib.check(_lib.load().pdr_reverse_update(got.data_ptr(), eps.data_ptr(), eps.stride(1), z.data_ptr(),
+                                                  a.data_ptr(), b.data_ptr(), c.data_ptr(), t.data_ptr(), B * N, mode,
+                                                  torch.cuda.current_stream().cuda_stream), "reverse_update")
+        assert torch.equal(got, want), (mode, step, float((got - want).abs().max()))

@@ -252,9 +252,28 @@ def test_metrics_python_surface(be):
             be.close(cost, g["emd_ragged"], 1)
             np.testing.assert_allclose(match.sum(1).cpu().numpy(), g["emd_match_rowsum"], rtol=1e-3, atol=1e-4)
             np.testing.assert_allclose(match.sum(2).cpu().numpy(), g["emd_match_colsum"], rtol=1e-3, atol=1e-4)
-    with pytest.raises(NotImplementedError):
-        with be.ops():
-            chamfer_loss_new.chamfer_distance(gen, gt, x_lengths=be.to(torch.tensor([256, 100, 256])))
+    # ragged clouds + normals (slow path; pytorch3d semantics of the reference :121-128, 152-155, 162-179): padded
+    # points are neither queries nor candidates; checked against a float64 brute force
+    lx, ly = torch.tensor([256, 100, 256]), torch.tensor([180, 256, 7])
+    gnorm = torch.Generator().manual_seed(44)
+    nx = torch.nn.functional.normalize(torch.randn(3, 256, 3, generator=gnorm), dim=2)
+    ny = torch.nn.functional.normalize(torch.randn(3, 256, 3, generator=gnorm), dim=2)
+    with be.ops():
+        cx, cy, cn = chamfer_loss_new.chamfer_distance(gen, gt, x_lengths=be.to(lx), y_lengths=be.to(ly),
+                                                       x_normals=be.to(nx), y_normals=be.to(ny))
+    g64, t64 = gen.double().cpu(), gt.double().cpu()
+    ex = ey = en = 0.0
+    for n in range(3):
+        a, b = g64[n, :lx[n]], t64[n, :ly[n]]
+        d = ((a[:, None] - b[None]) ** 2).sum(-1)
+        ex += d.min(1).values.sum() / lx[n] / 3
+        ey += d.min(0).values.sum() / ly[n] / 3
+        ca = torch.nn.functional.cosine_similarity(nx[n, :lx[n]].double(), ny[n, :ly[n]].double()[d.argmin(1)], dim=1)
+        cb = torch.nn.functional.cosine_similarity(ny[n, :ly[n]].double(), nx[n, :lx[n]].double()[d.argmin(0)], dim=1)
+        en += ((1 - ca.abs()).sum() / lx[n] + (1 - cb.abs()).sum() / ly[n]) / 3
+    np.testing.assert_allclose(float(cx), float(ex), rtol=1e-5)
+    np.testing.assert_allclose(float(cy), float(ey), rtol=1e-5)
+    np.testing.assert_allclose(float(cn), float(en), rtol=1e-4)
     with pytest.raises(ValueError):
         chamfer_loss_new.chamfer_distance(gen, gt, batch_reduction="max")
 

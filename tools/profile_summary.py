@@ -50,6 +50,34 @@ def counters(path, wanted):
     return acc
 
 
+def timeline(out, tag):
+    """<tag>_timeline.json: every kernel of ONE replayed reverse step (the last complete one of the --stats pass):
+    [short name, start us relative to the step's first kernel, duration us, queue id].  A step ends with the
+    reverse_update kernel; its kernels may run on several hardware queues (geometry side stream)."""
+    src = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_trace.csv"), recursive=True)
+    if not src:
+        return
+    rows = []
+    for r in csv.DictReader(open(src[0])):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if "reverse_update" in r[2]]
+    if len(ends) < 3:
+        return
+    lo, hi = ends[-2] + 1, ends[-1]
+    # the step counter decrement (one tiny torch kernel) follows the update: include up to the next kernel start
+    step = rows[lo:hi + 1]
+    t0 = step[0][0]
+    tl = [[n, round((a - t0) / 1e3, 2), round((b - a) / 1e3, 2), q] for a, b, n, q in step]
+    span = (max(r[1] for r in step) - t0) / 1e3
+    busy = {}
+    for a, b, n, q in step:
+        busy[q] = busy.get(q, 0.0) + (b - a) / 1e3
+    json.dump({"note": "one hipGraph-replayed reverse step, rocprofv3 kernel trace; [kernel, start_us, dur_us, queue]",
+               "span_us": round(span, 1), "kernels": len(tl), "busy_us_per_queue": {k: round(v, 1) for k, v in busy.items()},
+               "timeline": tl}, open(os.path.join(out, tag + "_timeline.json"), "w"))
+
+
 def main():
     out, tag = sys.argv[1], sys.argv[2]
     stats_src = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -123,6 +151,7 @@ def main():
         ops = json.load(open(os.path.join(out, tag + "_op_roofline.json")))
     except (OSError, ValueError):
         pass
+    timeline(out, tag)
     json.dump({"note": "step kernels: rocprofv3 --kernel-trace --stats of bench.py (hipGraph replay) joined with the "
                        "PMC passes; op rows: tools/op_roofline.py (HIP events, BASELINE sizes). Peaks: HBM 8 TB/s, "
                        "fp32 MFMA = fp32 VALU = 157.3 TFLOP/s",
