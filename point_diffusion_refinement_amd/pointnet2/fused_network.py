@@ -59,6 +59,9 @@ AHEAD_LEVEL = int(__import__("os").environ.get("PDR_AHEAD_LEVEL", "99"))
 # what rounds of this code did before; kept for A/B and as the cross-check of the tests).
 FUSE_CONDITION_BRANCH = __import__("os").environ.get("PDR_FUSE_CONDITION_BRANCH", "1") == "1"
 USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1"
+# Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
+# FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
+EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "1") == "1"
 
 
 def _stream():
@@ -311,6 +314,19 @@ class EmbeddingBank:
         src = {"t": t_emb, "c": c_emb, "c2": c2_emb}
         self.out = {k: F.linear(src[k], self.W[k], self.b[k]) for k in self.W}
 
+    def evaluate_kind(self, kind, src, static=False):
+        """One embedding kind.  static=True: the result is written IN PLACE into the buffer of the previous call
+        (same shape), so that a captured hipGraph -- which does not contain this GEMM -- keeps reading a valid
+        address whose contents follow the batch."""
+        if kind not in self.W:
+            return
+        val = F.linear(src, self.W[kind], self.b[kind])
+        old = self.out.get(kind)
+        if static and old is not None and old.shape == val.shape and old.device == val.device:
+            old.copy_(val)
+        else:
+            self.out[kind] = val
+
     def get(self, handle):
         """(tensor, offset, ld) of the (B, C) block of `handle`."""
         if handle is None:
@@ -527,8 +543,19 @@ class SplitFirstConv:
         run_layer(u_in, self.U, out=(buf, 0))
         return buf
 
+    def query_tables(self, query_xyz, has_v0):
+        """[V | V0] (B*m, ld or 2 ld): the per-QUERY half of the conv (coordinates and static weights only)."""
+        B, m, _ = query_xyz.shape
+        ld = _ldy(self.U.Cout)
+        q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
+        V2 = torch.empty((B * m, 2 * ld if has_v0 else ld), dtype=torch.float32, device=query_xyz.device)
+        run_layer(q_in, self.V, out=(V2, 0))
+        if has_v0:
+            run_layer(q_in, self.V0, out=(V2, ld))
+        return V2
+
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
-                 virtual=False, res=None, U=None):
+                 virtual=False, res=None, U=None, V2=None):
         """-> (Y1, partial, tiles_per_batch).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
         consumers read as a gathered source (only the GroupNorm moments are computed here)."""
         lib = _lib.load()
@@ -537,12 +564,10 @@ class SplitFirstConv:
         if U is None:
             U = self.source_table(src_feats_cl, src_xyz)
         ld = U.shape[1]
-        q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
         has_v0 = counts is not None
-        V2 = torch.empty((B * m, 2 * ld if has_v0 else ld), dtype=torch.float32, device=U.device)   # [V | V0]
-        run_layer(q_in, self.V, out=(V2, 0))
-        if has_v0:
-            run_layer(q_in, self.V0, out=(V2, ld))
+        if V2 is None:
+            V2 = self.query_tables(query_xyz, has_v0)
+        assert V2.shape == (B * m, 2 * ld if has_v0 else ld)
         ldv = V2.shape[1]
         rpb = m * K
         tpb = (rpb + 127) // 128
@@ -631,7 +656,14 @@ class FusedGroupedBlock:
     def neighbours(self, src_xyz, new_xyz):
         return _ext.ball_query(new_xyz, src_xyz, self.radius, self.nsample)
 
-    def prepare(self, src_xyz, src_feats_cl, new_xyz, bank, subset, neigh=None):
+    def query_tables(self, src_feat_width, new_xyz, subset):
+        """Per-query tables of the first conv for queries `new_xyz` (needs coordinates only): lets the caller issue
+        these small launches early.  None when the split first conv is off."""
+        if not USE_SPLIT_FIRST:
+            return None
+        return self._make_split(src_feat_width).query_tables(new_xyz, has_v0=not subset)
+
+    def prepare(self, src_xyz, src_feats_cl, new_xyz, bank, subset, neigh=None, V2=None):
         """Everything that does not involve the QUERY features: grouping, the shared MLP and the value half of the
         attention.  For the feature-transfer blocks this depends on coordinates and static tables only, so it can
         run ahead of the feature path on another stream."""
@@ -643,7 +675,7 @@ class FusedGroupedBlock:
             Y1, part1, tpb1 = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                     self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                     res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
-                                    U=self.static_U)
+                                    U=self.static_U, V2=V2)
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
         else:
             G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
@@ -658,8 +690,8 @@ class FusedGroupedBlock:
                        self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"])
         return out.view(B, m, -1)
 
-    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None):
-        return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh), query_feats_cl)
+    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
+        return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh, V2=V2), query_feats_cl)
 
 
 class FusedKnnFP:
@@ -750,6 +782,7 @@ class FusedCloudConditionNet:
         self._synced = False
         self._side = None
         self.return_strided_eps = False
+        self._label_key = None
 
     def _side_stream(self):
         if self._side is None:
@@ -786,6 +819,8 @@ class FusedCloudConditionNet:
             for i, blk in enumerate(self.dec_map):
                 blk.prepare_static_source(net.l_uvw[i], self.dec_cl[i])
             _XYZ4.clear()
+            # fc_condition(global feature) of every block: one GEMM per BATCH (static buffer, see _embeddings)
+            self.bank.evaluate_kind("c", net.global_feature, static=True)
         self._synced = True
 
     def _condition_branch(self, condition):
@@ -832,6 +867,24 @@ class FusedCloudConditionNet:
             if not use_retained_condition_feature:
                 self.reset_cond_features()
 
+    def _embeddings(self, ts, label):
+        """Step / condition / class embeddings of every block (EmbeddingBank).  Only the step embedding changes
+        from step to step: the condition (global feature) GEMM is refreshed by sync_condition once per batch, the
+        class-embedding GEMM when the label tensor changed (identity + version), both IN PLACE."""
+        net, hp, bank = self.net, self.net.hparams, self.bank
+        if ts is not None and hp['include_t']:
+            t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
+            t_emb = net.activation(net.fc_t2(t_emb))
+            bank.evaluate_kind("t", t_emb)
+        # (the key holds the tensor itself: while it is referenced here its address cannot be recycled)
+        key = (label, label._version)
+        if self._label_key is None or self._label_key[0] is not label or self._label_key[1] != label._version \
+                or "c2" not in bank.out:
+            bank.evaluate_kind("c2", net.class_emb(label), static=True)
+            self._label_key = key
+        if "c" not in bank.out:
+            bank.evaluate_kind("c", net.global_feature, static=True)
+
     def _forward_cached(self, pointcloud, condition, ts, label):
         net, hp, bank = self.net, self.net.hparams, self.bank
         B, N, _ = pointcloud.shape
@@ -844,6 +897,21 @@ class FusedCloudConditionNet:
             self.sync_condition()
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
         l_uvw = net.l_uvw
+
+        # ---- everything that is small and needs no geometry goes FIRST, before the side stream is forked ----------
+        # Measured on MI355X (rocprofv3 timeline of a replayed step, profiles/r2_timeline notes in DESIGN.md): while
+        # the geometry stream runs a long kernel with dependent successors queued behind it (the FPS chain), the
+        # dependent small launches of the OTHER stream are dispatched at one per ~55 us.  The step embedding chain
+        # (sin / cos / cat, two Linear + swish, the per-block fc(t_emb) GEMM) and the first block's per-query tables
+        # used to sit exactly there: ~15 launches = ~0.75 ms before the first large kernel of the step started.
+        # Issued ahead of the fork they run back to back (~5 us each).  The condition / class embeddings do not
+        # change between the steps of a batch: their GEMMs run once per batch into static buffers.
+        early = EARLY_EMBED
+        if early:
+            self._embeddings(ts, label)
+            v2_first = self.enc_map[0].query_tables(enc_cl[0].shape[2], xyz, subset=False)
+        else:
+            v2_first = None
 
         # ---- geometry prepass on a side stream -------------------------------------------------
         # FPS chain, every ball query and every kNN search depend on coordinates only.  They are
@@ -888,13 +956,9 @@ class FusedCloudConditionNet:
             ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
             ev_knn.record(side)
 
-        # ---- embeddings (independent of the geometry: evaluated while the side stream is already running)
-        t_emb = None
-        if ts is not None and hp['include_t']:
-            t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
-            t_emb = net.activation(net.fc_t2(t_emb))
-        class_emb = net.class_emb(label)
-        bank.evaluate(t_emb, net.global_feature, class_emb)
+        # ---- embeddings (A/B: PDR_EARLY_EMBED=0 issues them here, beside the running geometry stream)
+        if not early:
+            self._embeddings(ts, label)
 
         # ---- query-independent parts of the deep feature-transfer blocks, ahead of time on a third stream
         ahead = {}
@@ -913,18 +977,18 @@ class FusedCloudConditionNet:
                     ev.record(aux)
                     ahead[id(blk)] = (prep, ev)
 
-        def transfer(blk, l, cl, query):
+        def transfer(blk, l, cl, query, V2=None):
             hit = ahead.pop(id(blk), None)
             if hit is not None:
                 main.wait_event(hit[1])
                 return blk.finish(hit[0], query)
-            return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)])
+            return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
 
         # ---- feature path ------------------------------------------------------------------------
         main.wait_event(ev_first)
         l_feat = [feat0]
         for i, sa in enumerate(self.sa):
-            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i])
+            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=v2_first if i == 0 else None)
             if i == 0:
                 main.wait_event(ev_all)
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)

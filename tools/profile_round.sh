@@ -16,6 +16,10 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --warmup 3 --no-cpu-baseline --no-roofline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o s -- $BENCH --steps 20 > $OUT/${TAG}_stats.log 2>&1
 tail -1 $OUT/${TAG}_stats.log | cut -c1-200
+if [ -n "$PDR_PROFILE_QUICK" ]; then   # kernel stats + step timeline only (no counter passes)
+  cd $REPO && python tools/profile_summary.py $OUT $TAG && rm -rf $OUT/${TAG}_stats
+  exit 0
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc/$c -o p -- $BENCH --steps 2 > $OUT/${TAG}_pmc.$c.log 2>&1
   tail -1 $OUT/${TAG}_pmc.$c.log | cut -c1-120
