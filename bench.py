@@ -359,15 +359,13 @@ def main():
         try:
             s2, _ = build_sampler(device, not args.no_graph, precision="split_bf16")
             el2, _ = timed_steps(s2, args.steps, args.warmup)
-            rel = ((s2._x - x_now).abs() / (x_now.abs() + 1.0)).flatten(1).median(1).values.max()
             out["split_bf16"] = {"value": round(B * args.steps / el2, 2), "unit": "cloud-steps/s",
                                  "ms_per_step": round(el2 / args.steps * 1e3, 4),
                                  "completed_points_per_s_per_gpu": round(B * args.steps / el2 * N_POINTS / T_STEPS, 2),
-                                 "dtype": "bf16x3 MFMA (fp32 accumulate) for Cin >= 128 GEMMs, fp32 elsewhere",
-                                 "max_cloud_median_rel_diff_vs_f32_after_%d_steps" % (args.steps + max(args.warmup, 1) + 1):
-                                     float("%.3g" % float(rel)),
-                                 "note": "opt-in mode, NOT the headline; same noise seed is not shared, so the "
-                                         "difference includes one Philox stream offset"}
+                                 "dtype": "bf16x3 MFMA (hi/lo split of both operands, fp32 accumulate) for the 128-column "
+                                          "GEMM tiles with Cin >= 128, exact fp32 MFMA elsewhere",
+                                 "note": "opt-in precision='split_bf16', NOT the headline; parity bar in "
+                                         "tests/test_fused_gpu.py::test_split_bf16_*"}
             del s2
         except Exception as e:
             out["split_bf16"] = {"error": repr(e)}

@@ -241,6 +241,17 @@ int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float 
 int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,
                     int relu_col0, pdr_stream_t stream);
+/* pdr_fused_layer in SPLIT-bf16 arithmetic (opt-in, never the default): x . w is evaluated as xh wh + xh wl + xl wh
+ * with xh = bf16(x), xl = bf16(x - xh) (same for w) on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- about 16
+ * mantissa bits per product instead of 24.  `Wp`: the weights packed by the caller, 16-byte aligned: for every
+ * 128-column block cb and every K-chunk c (the input segments in order, each cut into chunks of 32 channels, the
+ * last one zero-padded) one 16-KiB block  [hi | lo] x [128 columns][32 k] bf16 (k contiguous, 64-byte rows) whose
+ * 16-byte granule g of column n is stored at position g ^ ((n >> 2) & 3);  block index = cb * nchunks + c.
+ * Available for the 128-column wave-specialised tiles (pdr_fused_layer_variant 4 and 5); returns PDR_EUNSUPPORTED
+ * otherwise -- callers then use pdr_fused_layer. */
+int pdr_fused_layer_bf16x3(const pdr_layer_in_t *in, long P, int Cin, const void *Wp, int nchunks,
+                           const float *bias, int Cout, float *Y, int ldy, float *partial, int relu_col0,
+                           pdr_stream_t stream);
 /* pdr_fused_layer whose output (the attention scores, D channels) is consumed in the epilogue:
  * out[q,:] = sum_k softmax_k(mask(scores))[k,:] * act(values[q*K+k,:]*vscale + vshift); the (P x D)
  * score tensor is never written.  K in {8,16,32}; counts (P/K) or NULL = all neighbours valid.

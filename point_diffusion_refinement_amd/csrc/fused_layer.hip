@@ -878,6 +878,31 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   return pdr::check_launch();
 }
 
+// pdr_fused_layer with SPLIT-bf16 arithmetic (opt-in): both GEMM operands are split into bf16 hi + lo parts and the
+// product is accumulated as xh wh + xh wl + xl wh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~16 mantissa
+// bits kept).  Wp = weight image of pdr-side packing (see include/pdr_hip.h), nchunks = K-chunks per column block.
+// Only the 128-column wave-specialised tiles carry this mode: PDR_EUNSUPPORTED otherwise (callers fall back to
+// the exact fp32 entry point).
+extern "C" int pdr_fused_layer_bf16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
+                                      const float* bias, int Cout, float* Y, int ldy, float* partial,
+                                      int relu_col0, pdr_stream_t stream) {
+  if (!Y || !Wp || nchunks <= 0 || reinterpret_cast<uintptr_t>(Wp) % 16 != 0) return PDR_EINVAL;
+  LayerPlan pl;
+  // (the fp32 weight arguments of the plan are placeholders: alignment-clean dummies)
+  const int prc = plan_layer(in, P, Cin, reinterpret_cast<const float*>(Wp), (Cout + 3) & ~3, Cout, Y, ldy, &pl);
+  if (prc != PDR_OK) return prc;
+  if (P == 0) return PDR_OK;
+  if (!pl.ws || (pl.t.id != 4 && pl.t.id != 5)) return PDR_EUNSUPPORTED;
+  int nch = 0;
+  for (int s = 0; s < in->n_seg; ++s) nch += (in->seg[s].C + 31) / 32;
+  if (nch != nchunks) return PDR_EINVAL;   // the image was packed for another segment structure
+  if (!pdr::launch_fused_layer_ws(pl.t.id, pl.radd, pl.gath, *in, Cin, reinterpret_cast<const float*>(Wp), nchunks,
+                                  bias, Cout, Y, ldy, partial, relu_col0, static_cast<int>(pl.ntiles), pl.ncol,
+                                  pdr::as_stream(stream), true))
+    return PDR_EUNSUPPORTED;
+  return pdr::check_launch();
+}
+
 // scores = prologue(X) . Wt + bias are consumed by the POOL epilogue:
 //   out[q, :] = sum_k softmax_k(mask(scores))[k, :] * act(values[q K + k, :] * vscale + vshift)
 // K in {8, 16, 32}; Cout = D (channels of scores, values and out).

@@ -58,13 +58,43 @@ __device__ __forceinline__ float vmax(float a, float b) {
   return r;
 }
 
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool GATH = false>
+// LDS image of the two pipeline stages.
+//   fp32 (exact):  A k-major [k][row] (+1 pad), W k-major [k][col]: one ds_read_b32 per MFMA operand element.
+//   SPLIT (bf16x3): every fp32 value x is held as hi = bf16(x), lo = bf16(x - hi); A and W are ROW-major
+//   [row][32 k] / [col][32 k] bf16 = 64-byte rows so that a lane's MFMA operand (8 consecutive k of one row) is ONE
+//   ds_read_b128.  Rows are unpadded; the 16-byte granule g of row r sits at position g ^ ((r >> 2) & 3): the 16
+//   lanes of a ds_read_b128 service group (rows distinct mod 16, same g) then hit 16 distinct 16-byte slots of the
+//   256-byte bank row, and a producer's 16-lane ds_write_b64 group covers two whole rows = 32 distinct banks.
+template <bool SPLIT, int KC, int TM, int TN>
+struct StageMem;
+template <int KC, int TM, int TN>
+struct StageMem<false, KC, TM, TN> {
+  float As[2][KC][TM + 1];
+  __attribute__((aligned(16))) float Bs[2][KC][TN];
+};
+template <int KC, int TM, int TN>
+struct StageMem<true, KC, TM, TN> {
+  static_assert(KC == 32, "split layout: 32 bf16 = 64-byte rows");
+  __attribute__((aligned(16))) unsigned char A[2][2][TM * 64];   // [stage][hi / lo][row][64 B]
+  __attribute__((aligned(16))) unsigned char B[2][2][TN * 64];   // [stage][hi / lo][col][64 B]
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// byte offset of k-granule g (8 bf16 = 16 B) of row r inside a [rows][64 B] image
+__device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ ((r >> 2) & 3)) << 4); }
+
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool GATH = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
     float* __restrict__ partial, int relu_col0, int n_row_tiles) {
+  // SPLIT: `Wt` points at the packed bf16 hi / lo weight image (pdr_pack_weights_bf16x3: per column block and
+  // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
   constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
+  static_assert(!SPLIT || TN == 128, "split image: 128-column blocks");
   constexpr int C4 = KC / 4;          // float4 columns of an A chunk
   constexpr int PT = 256;             // producer threads: all four producer waves stage every chunk
   constexpr int VSTEP = PT / C4;      // rows covered per step
@@ -72,8 +102,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
   constexpr int TN4 = TN / 4;
   constexpr int WPT4 = (KC * TN4 + PT - 1) / PT;
   static_assert(TM % VSTEP == 0, "tile rows");
-  __shared__ float As[2][KC][TM + 1];
-  __shared__ __attribute__((aligned(16))) float Bs[2][KC][TN];
+  __shared__ StageMem<SPLIT, KC, TM, TN> sm;
   __shared__ float red[WR][TN][2];
   __shared__ int epi_ticket;          // consumer waves that finished the statistics of a tile (4 per tile)
   // per consumer wave: half of a 32 x 32 accumulator tile, row-major, for 16-byte coalesced stores
@@ -97,7 +126,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 #endif
 
   // cursor over (tile, segment, channel offset)
-  struct Cur { int tile, sg, ks, cbase; };
+  struct Cur { int tile, sg, ks, cbase, ci; };   // ci: chunk number within the tile (0 .. nch-1)
   // branch-free (scalar selects): a branch between a fetch and the following commit makes the
   // compiler's wait-count pass fall back to vmcnt(0), which would drain the prefetch
   auto advance = [&](Cur& c, bool really = true) {
@@ -110,6 +139,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     n.cbase = tile_end ? 0 : (seg_end ? c.cbase + segC : c.cbase);
     n.sg = tile_end ? 0 : (seg_end ? c.sg + 1 : c.sg);
     n.tile = tile_end ? c.tile + static_cast<int>(gridDim.x) : c.tile;
+    n.ci = tile_end ? 0 : c.ci + 1;
+    c.ci = really ? n.ci : c.ci;
     c.ks = really ? n.ks : c.ks;
     c.cbase = really ? n.cbase : c.cbase;
     c.sg = really ? n.sg : c.sg;
@@ -212,7 +243,10 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           seg.ptr + (f_g ? static_cast<long>(b) * seg.g_nsrc : (row0 >> shift)) * seg.ld + c.ks);
       const int zrow = f_g ? seg.g_zrow - b * seg.g_nsrc : 0;    // the zero row, relative to this cloud
       const int v0d = (f_g && seg.gV0) ? static_cast<int>(seg.gV0 - seg.gV) : 0;
-      const char* wb = reinterpret_cast<const char*>(Wt + static_cast<long>(c.cbase + c.ks) * ldw + n0);
+      // SPLIT: chunk image number (column block, chunk) of the packed weights; 16 KiB each, copied linearly
+      const char* wb = SPLIT ? reinterpret_cast<const char*>(Wt) +
+                                   (static_cast<long>(blockIdx.y) * ldw + c.ci) * (2L * TN * 64)
+                             : reinterpret_cast<const char*>(Wt + static_cast<long>(c.cbase + c.ks) * ldw + n0);
       unsigned ao[APT4], ro[RADD ? APT4 : 1], wo[WPT4], po[4], vo[GATH ? APT4 : 1];
       if (Rkmax == KC && nvalid == TM) {
         // ---- fast path (uniform): the precomputed per-thread offsets
@@ -245,7 +279,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           for (int i = 0; i < APT4; ++i) ro[i] = r_off[i];
         }
 #pragma unroll
-        for (int i = 0; i < WPT4; ++i) wo[i] = w_off[i];
+        for (int i = 0; i < WPT4; ++i) wo[i] = SPLIT ? static_cast<unsigned>(pt + PT * i) * 16u : w_off[i];
       } else {
         // ---- general path: partial chunk (last of a segment) or partial row tile
         const int cl = 4 * vc4;                                   // relative to ks
@@ -272,7 +306,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
         for (int i = 0; i < WPT4; ++i) {
           const int e = pt + PT * i;
           const int k = e / TN4, n4 = e - k * TN4;
-          wo[i] = static_cast<unsigned>(min(k, Rkmax - 1) * ldw + min(4 * n4, nmax)) * 4u;
+          wo[i] = SPLIT ? static_cast<unsigned>(pt + PT * i) * 16u
+                        : static_cast<unsigned>(min(k, Rkmax - 1) * ldw + min(4 * n4, nmax)) * 4u;
         }
       }
 #pragma unroll
@@ -330,7 +365,24 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             if constexpr (ADD) v = v + Rpa[j];
             if constexpr (RADD) v = v + q[j];
             if constexpr (MASKED) v = j < Rcvalid ? v : 0.0f;
-            As[st][4 * vc4 + j][vr0 + VSTEP * i] = v;
+            if constexpr (SPLIT) x[j] = v;
+            else sm.As[st][4 * vc4 + j][vr0 + VSTEP * i] = v;
+          }
+          if constexpr (SPLIT) {
+            // x = hi + lo + O(2^-17 |x|): hi = bf16(x) (round to nearest even), lo = bf16(x - hi); the four
+            // channels of this thread are 4 consecutive k of row r: 8 bytes of the hi image, 8 of the lo image
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 v01 = {x[0], x[1]}, v23 = {x[2], x[3]};
+            const bf16x2 h01 = __builtin_convertvector(v01, bf16x2), h23 = __builtin_convertvector(v23, bf16x2);
+            const f2 r01 = v01 - __builtin_convertvector(h01, f2), r23 = v23 - __builtin_convertvector(h23, f2);
+            const bf16x2 l01 = __builtin_convertvector(r01, bf16x2), l23 = __builtin_convertvector(r23, bf16x2);
+            const int r = vr0 + VSTEP * i;
+            const int off = split_off(r, vc4 >> 1) + ((vc4 & 1) << 3);
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u2*>(&sm.A[st][0][off]) =
+                u2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+            *reinterpret_cast<u2*>(&sm.A[st][1][off]) =
+                u2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
           }
         }
       };
@@ -340,11 +392,18 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       else if (has_pre) stage_a(F(), T(), T());
       else if (has_add) stage_a(F(), F(), T());
       else stage_a(F(), F(), F());
+      if constexpr (SPLIT) {
+        // the packed image is already in LDS layout ([hi | lo][col][64 B], granules swizzled): linear copy
+        unsigned char* wdst = &sm.B[st][0][0];
 #pragma unroll
-      for (int i = 0; i < WPT4; ++i) {
-        const int e = pt + PT * i;
-        const int k = e / TN4, n4 = e - k * TN4;
-        if (KC * TN4 % PT == 0 || e < KC * TN4) *reinterpret_cast<f32x4*>(&Bs[st][k][4 * n4]) = Rrw[i];
+        for (int i = 0; i < WPT4; ++i) *reinterpret_cast<f32x4*>(wdst + (pt + PT * i) * 16) = Rrw[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < WPT4; ++i) {
+          const int e = pt + PT * i;
+          const int k = e / TN4, n4 = e - k * TN4;
+          if (KC * TN4 % PT == 0 || e < KC * TN4) *reinterpret_cast<f32x4*>(&sm.Bs[st][k][4 * n4]) = Rrw[i];
+        }
       }
     };
 
@@ -352,7 +411,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // the next chunk, barrier.  The staging math is spread over all four producer waves because its
     // LATENCY (not its issue cost) is what can delay the barrier: next to two MFMA-bound waves a
     // VALU instruction waits ~a whole MFMA issue slot.
-    Cur co{static_cast<int>(blockIdx.x), 0, 0, 0};
+    Cur co{static_cast<int>(blockIdx.x), 0, 0, 0, 0};
     fetch(co);
     for (int g = 0; g < G; ++g) {
       PDR_T(1, 4 * g + 0);
@@ -390,24 +449,54 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_r[j];
 
-  Cur cur{static_cast<int>(blockIdx.x), 0, 0, 0};
+  Cur cur{static_cast<int>(blockIdx.x), 0, 0, 0, 0};
   for (int g = 0; g < G; ++g) {
     PDR_T(0, 4 * g + 0);
     __syncthreads();   // B(g)
     PDR_T(0, 4 * g + 1);
     const int st = g & 1;
-    const int ksteps = (min(KC, in.seg[cur.sg].C - cur.ks) + 1) >> 1;
-    for (int kk = 0; kk < ksteps; ++kk) {
-      float a[RT], w[CT];
+    if constexpr (SPLIT) {
+      // bf16x3: x . w = xh wh + xh wl + xl wh (+ xl wl ~ 2^-16 relative, dropped), fp32 accumulation, on
+      // v_mfma_f32_32x32x16_bf16: lane (il, hi) supplies 8 consecutive k (k = 16 ks + 8 hi ...) of its row / column
+      const int ksteps16 = (min(KC, in.seg[cur.sg].C - cur.ks) + 15) >> 4;
+      for (int ks = 0; ks < ksteps16; ++ks) {
+        bf16x8 ah[RT], al[RT], wh[CT], wl[CT];
+        const int gq = 2 * ks + hi;
 #pragma unroll
-      for (int i = 0; i < RT; ++i) a[i] = As[st][2 * kk + hi][(wr * RT + i) * 32 + il];
+        for (int i = 0; i < RT; ++i) {
+          const int off = split_off((wr * RT + i) * 32 + il, gq);
+          ah[i] = *reinterpret_cast<const bf16x8*>(&sm.A[st][0][off]);
+          al[i] = *reinterpret_cast<const bf16x8*>(&sm.A[st][1][off]);
+        }
 #pragma unroll
-      for (int j = 0; j < CT; ++j) w[j] = Bs[st][2 * kk + hi][(wc * CT + j) * 32 + il];
+        for (int j = 0; j < CT; ++j) {
+          const int off = split_off((wc * CT + j) * 32 + il, gq);
+          wh[j] = *reinterpret_cast<const bf16x8*>(&sm.B[st][0][off]);
+          wl[j] = *reinterpret_cast<const bf16x8*>(&sm.B[st][1][off]);
+        }
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < CT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], w[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < CT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
+      const int ksteps = (min(KC, in.seg[cur.sg].C - cur.ks) + 1) >> 1;
+      for (int kk = 0; kk < ksteps; ++kk) {
+        float a[RT], w[CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) a[i] = sm.As[st][2 * kk + hi][(wr * RT + i) * 32 + il];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) w[j] = sm.Bs[st][2 * kk + hi][(wc * CT + j) * 32 + il];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], w[j], acc[i][j], 0, 0, 0);
+      }
     }
     PDR_T(0, 4 * g + 2);
     if (last_of_tile(cur)) {
@@ -629,28 +718,38 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
 }
 
 // Launches the wave-specialised kernel for tile variant `id`.  Returns false when the variant has no
-// wave-specialised instantiation.
+// wave-specialised instantiation.  split: bf16x3 arithmetic (Wt = packed weight image, ldw = chunks per column
+// block); instantiated for the 128-column tile variants 4 and 5 only.
 bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
                            int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
-                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s) {
+                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split) {
   if (!fused_layer_ws_supported(id, radd, gath, in, Cin)) return false;
+  if (split && id != 4 && id != 5) return false;
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   const long cap = (512 + ncol - 1) / ncol;
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
-#define PDR_WS(RT, CT, WR, WC, KC)                                                                      \
-  do {                                                                                                  \
-    if (gath)                                                                                           \
-      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, true>), grid, dim3(512), 0,  \
-                         s, in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);     \
-    else if (radd)                                                                                      \
-      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, true>), grid, dim3(512), 0, s, in,  \
-                         Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);            \
-    else                                                                                                \
-      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false>), grid, dim3(512), 0, s, in, \
-                         Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles);            \
+#define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
+  hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles)
+#define PDR_WS(RT, CT, WR, WC, KC)                            \
+  do {                                                        \
+    if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, true, false);  \
+    else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, false, false); \
+    else PDR_WS_K(RT, CT, WR, WC, KC, false, false, false);   \
   } while (0)
+#define PDR_WS_SPLIT(RT, CT, WR, WC, KC)                      \
+  do {                                                        \
+    if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, true, true);   \
+    else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, false, true); \
+    else PDR_WS_K(RT, CT, WR, WC, KC, false, false, true);    \
+  } while (0)
+  if (split) {
+    if (id == 4) PDR_WS_SPLIT(2, 2, 2, 2, 32);
+    else PDR_WS_SPLIT(1, 2, 2, 2, 32);
+    return true;
+  }
   switch (id) {
     case 0: PDR_WS(2, 1, 4, 1, 16); return true;
     case 1: PDR_WS(2, 2, 4, 1, 16); return true;
@@ -661,6 +760,8 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     default: return false;
   }
 #undef PDR_WS
+#undef PDR_WS_SPLIT
+#undef PDR_WS_K
 }
 
 }  // namespace pdr

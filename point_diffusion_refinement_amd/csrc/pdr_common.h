@@ -33,7 +33,8 @@ inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream
 bool fused_layer_ws_supported(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin);
 bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,
                            const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
-                           float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s);
+                           float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s,
+                           bool split = false);
 
 // ---- DPP wave reductions (wave64, gfx9 row_shr / row_bcast) -------------------
 // After wave_max_*: lane 63 holds the maximum; callers broadcast with readlane.

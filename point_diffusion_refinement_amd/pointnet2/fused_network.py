@@ -61,7 +61,11 @@ FUSE_CONDITION_BRANCH = __import__("os").environ.get("PDR_FUSE_CONDITION_BRANCH"
 USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1"
 # Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
 # FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
-EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "1") == "1"
+# Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
+# 11.57 ms issued ahead of the fork (B = 8: 5.82 vs 5.92) -- the later start of the FPS chain costs more than the
+# embedding launches save -- so the default stays OFF; the rocprofv3 timeline that suggested the opposite turned
+# out to be distorted by the tracer.
+EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
 
 
 def _stream():
@@ -201,6 +205,61 @@ class Conv:
         self.widths = [w.shape[0] for w in ws]
 
 
+# Arithmetic of the wide GEMMs of the forward in flight: "f32" (exact fp32 MFMA, default) or "split_bf16"
+# (opt-in; FusedCloudConditionNet(precision=...) sets it around its forward).  See pack_bf16x3 / run_layer.
+_PRECISION = ["f32"]
+SPLIT_MIN_CIN = 128          # layers with fewer input channels are HBM-bound: nothing to gain, stay exact
+
+
+def pack_bf16x3(Wt, Cout, seg_widths):
+    """Weight image of pdr_fused_layer_bf16x3 (layout contract in include/pdr_hip.h): Wt (Cin, >= Cout) fp32 ->
+    int16 tensor [column block][chunk][hi | lo][128 cols][32 k], k-granules XOR-swizzled; returns (image, chunks)."""
+    KC, TN = 32, 128
+    W = Wt[:, :Cout].float()
+    hi = W.to(torch.bfloat16)                                   # round to nearest even, as v_cvt_pk_bf16_f32
+    lo = (W - hi.float()).to(torch.bfloat16)
+    chunks, k = [], 0
+    for C in seg_widths:
+        for ks in range(0, C, KC):
+            chunks.append((k + ks, min(KC, C - ks)))
+        k += C
+    assert k == W.shape[0]
+    ncb = (Cout + TN - 1) // TN
+    img = torch.zeros((ncb, len(chunks), 2, TN, KC), dtype=torch.bfloat16, device=Wt.device)
+    for cb in range(ncb):
+        n0 = cb * TN
+        nn_ = min(TN, Cout - n0)
+        for ci, (k0, km) in enumerate(chunks):
+            img[cb, ci, 0, :nn_, :km] = hi[k0:k0 + km, n0:n0 + nn_].t()
+            img[cb, ci, 1, :nn_, :km] = lo[k0:k0 + km, n0:n0 + nn_].t()
+    # granule g (8 k = 16 bytes) of column n is stored at position g ^ ((n >> 2) & 3)  (XOR: an involution)
+    img = img.view(ncb, len(chunks), 2, TN, 4, 8)
+    n = torch.arange(TN, device=Wt.device)
+    pos = torch.arange(4, device=Wt.device)[None, :] ^ ((n >> 2) & 3)[:, None]          # [n][p] -> source granule
+    img = img.gather(4, pos[None, None, None, :, :, None].expand_as(img)).contiguous()
+    return img.view(torch.int16).reshape(-1), len(chunks)
+
+
+def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, relu_col0):
+    """Try the bf16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel)."""
+    if _PRECISION[0] != "split_bf16" or conv.Cin < SPLIT_MIN_CIN:
+        return False
+    if lib.pdr_fused_layer_variant(act.rpb, conv.Cout) not in (4, 5):
+        return False
+    key = tuple(sg[2] for sg in act.segs)
+    cache = conv.__dict__.setdefault("_bf16x3", {})
+    if key not in cache:
+        cache[key] = pack_bf16x3(conv.Wt, conv.Cout, key)
+    img, nch = cache[key]
+    rc = lib.pdr_fused_layer_bf16x3(ctypes.byref(li), act.P, conv.Cin, img.data_ptr(), nch, conv.bias.data_ptr(),
+                                    conv.Cout, y_ptr, ldy, partial.data_ptr() if partial is not None else None,
+                                    relu_col0, _stream())
+    if rc == _lib.PDR_EUNSUPPORTED:
+        return False
+    _lib.check(rc, "fused_layer_bf16x3")
+    return True
+
+
 def _ldy(Cout):
     # rows of wide, odd-width outputs (105, 140, 297 ... = [first | res | key] GEMMs) start on
     # 128-byte boundaries: pad the leading dimension, consumers address columns through `ld`
@@ -229,10 +288,11 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
     if stats:
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
-    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
-                                   conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
-                                   partial.data_ptr() if stats else None,
-                                   conv.Cout if relu_col0 is None else relu_col0, _stream()), "fused_layer")
+    rc0 = conv.Cout if relu_col0 is None else relu_col0
+    if not _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, rc0):
+        _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
+                                       conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
+                                       partial.data_ptr() if stats else None, rc0, _stream()), "fused_layer")
     return Y, partial, tpb
 
 
@@ -810,6 +870,8 @@ class FusedCloudConditionNet:
 
         self.enc_cl = convert(self.enc_cl, net.encoder_cond_features)
         self.dec_cl = convert(self.dec_cl, net.decoder_cond_features)
+        saved_precision = _PRECISION[0]
+        _PRECISION[0] = self.precision
         # the feature-transfer blocks read these static clouds as their SOURCE: the per-source half of their
         # first conv (SplitFirstConv.source_table) is evaluated here, once per batch, not once per step
         with torch.no_grad():
@@ -821,6 +883,7 @@ class FusedCloudConditionNet:
             _XYZ4.clear()
             # fc_condition(global feature) of every block: one GEMM per BATCH (static buffer, see _embeddings)
             self.bank.evaluate_kind("c", net.global_feature, static=True)
+        _PRECISION[0] = saved_precision
         self._synced = True
 
     def _condition_branch(self, condition):
@@ -859,11 +922,15 @@ class FusedCloudConditionNet:
                 # first step of a batch (condition branch not retained yet): reference-layout path
                 return net(pointcloud, condition, ts=ts, label=label,
                            use_retained_condition_feature=use_retained_condition_feature)
-            _XYZ4.clear()
-            self._condition_branch(condition)
+        saved = _PRECISION[0]
+        _PRECISION[0] = self.precision
         try:
+            if fresh:
+                _XYZ4.clear()
+                self._condition_branch(condition)
             return self._forward_cached(pointcloud, condition, ts, label)
         finally:
+            _PRECISION[0] = saved
             if not use_retained_condition_feature:
                 self.reset_cond_features()
 

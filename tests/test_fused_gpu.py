@@ -416,3 +416,79 @@ def test_attention_pool_matches_masked_softmax(cuda, B, npoint, K, D, ld, use_co
         s = torch.where(mask, torch.full_like(s, -1e9), s)
     want = (torch.softmax(s, dim=2) * v).sum(2).view(B * npoint, D)
     assert _rel(out.double(), want) < 2e-6
+
+
+# ------------------------------------------------------------------ split-bf16 (opt-in) arithmetic
+@pytest.mark.parametrize("P,Cin,Cout,rpb,segs", [(1024, 128, 128, 256, (128,)), (2048, 331, 331, 1024, (171, 160)),
+                                                 (512, 512, 512, 64, (512,)), (4096, 203, 128, 4096, (200, 3)),
+                                                 (1 << 16, 256, 256, 8192, (128, 128))])
+def test_split_bf16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch):
+    """pdr_fused_layer_bf16x3 (x . w = xh wh + xh wl + xl wh on bf16 MFMA, fp32 accumulate): every element within
+    1e-4 of the float64 result RELATIVE TO THE ROW's |x| . |w| scale (the exact fp32 kernel sits at ~1e-6), incl.
+    multi-segment inputs, a partial last chunk, the prologue and a residual; statistics as in the exact kernel."""
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    B = P // rpb
+    xs, off = [], 0
+    for C in segs:
+        ld = (C + 3) // 4 * 4
+        t = torch.full((P, ld), float("nan"))
+        t[:, :C] = torch.randn(P, C, generator=g)
+        xs.append((t.to(cuda), C, ld))
+    scale, shift, add = (torch.randn(B, Cin, generator=g).to(cuda) for _ in range(3))
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    bias = torch.randn(Cout, generator=g).to(cuda)
+    conv = _conv(W, bias)
+    bidx = torch.arange(P, device=cuda) // rpb
+    x = torch.cat([t[:, :C] for t, C, _ in xs], 1)
+    act = FN.Act([(t, 0, C, ld, 1) for t, C, ld in xs], P, B, rpb, scale=scale, shift=shift, add=add, add_ld=Cin,
+                 post_relu=True)
+    xin = (x * scale[bidx] + shift[bidx]).relu() + add[bidx]
+    ref = xin.double() @ W.t().double() + bias.double()
+    bound = (xin.abs().double() @ W.t().abs().double()) + 1.0
+    monkeypatch.setitem(FN._PRECISION, 0, "split_bf16")
+    lib = _lib.load()
+    Y = torch.empty((P, FN._ldy(Cout)), device=cuda)
+    tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+    tpb = (rpb + tm - 1) // tm
+    part = torch.empty((B * tpb, Cout, 2), device=cuda)
+    assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), "split path not taken"
+    err = ((Y[:, :Cout].double() - ref).abs() / bound)
+    assert float(err.max()) < 1e-4, float(err.max())
+    got = part.view(B, tpb, Cout, 2).double().sum(1)
+    assert _rel(got[..., 0], ref.view(B, rpb, Cout).sum(1)) < 1e-3
+    # and the exact kernel on the same input is (much) closer: the mode really changes the arithmetic
+    monkeypatch.setitem(FN._PRECISION, 0, "f32")
+    Ye, _, _ = FN.run_layer(act, conv, stats=True)
+    exact = ((Ye[:, :Cout].double() - ref).abs() / bound)
+    assert float(exact.max()) < 2e-6 and float(err.max()) > float(exact.max())
+
+
+def test_split_bf16_network_and_sampler(cuda):
+    """Opt-in precision='split_bf16' on the shipped DDPM architecture: eps vs the exact fused network within the
+    network-level bar, and the graph-captured sampler vs the reference-style loop under the same thresholds as the
+    exact mode (test_fused_network_ddpm_config_and_graphed_sampler)."""
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
+    exact = FN.FusedCloudConditionNet(net)
+    split = FN.FusedCloudConditionNet(net, precision="split_bf16")
+    x, cond, label = synthetic_batch(2, seed=3, device=cuda)
+    ts = torch.tensor([500.0, 20.0], device=cuda)
+    a, ref = _cached_eps(net, exact, x, cond, ts, label)
+    b, _ = _cached_eps(net, split, x, cond, ts, label)
+    for got, want in ((b, a), (b, ref)):
+        err = ((got - want).abs() / (want.abs() + 1.0))
+        assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
+    assert float((a - b).abs().max()) > 0.0                               # the split kernels really ran
+    dh = util.calc_diffusion_hyperparams(6, 1e-4, 0.02)
+    util.set_device(cuda)
+    util.set_noise_source('cpu')
+    torch.manual_seed(77)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        want = util.sampling(net, (2, 2048, 3), dh, label=label, verbose=False, condition=cond)
+    util.set_device(None)
+    torch.manual_seed(77)
+    got = GraphedReverseSampler(split, dh, noise='cpu', use_graph=True).sample((2, 2048, 3), cond, label)
+    per_cloud = ((got - want).abs() / (want.abs() + 1.0)).flatten(1)
+    assert (per_cloud.median(1).values < 1e-4).all(), per_cloud.median(1).values
+    assert float(per_cloud.max()) < 0.5, per_cloud.max(1).values

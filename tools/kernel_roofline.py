@@ -42,10 +42,8 @@ def _b(x):
 def _layer_symbol(plan):
     ws, vid, radd, gath, vec, split = plan
     t = ", ".join(str(v) for v in _VARIANT[vid])
-    if ws and split:
-        return "fused_layer_ws_bf16x3_kernel<%s, %s, %s>" % (t, _b(radd), _b(gath))
     if ws:
-        return "fused_layer_ws_kernel<%s, %s, %s>" % (t, _b(radd), _b(gath))
+        return "fused_layer_ws_kernel<%s, %s, %s%s>" % (t, _b(radd), _b(gath), ", true" if split else "")
     return "fused_layer_kernel<%s, %s, %s, %s, false>" % (t, _b(radd), _b(vec), _b(gath))
 
 
@@ -66,6 +64,15 @@ def _work(name, args, lib):
         if li.rseg.ptr:
             byt += 4.0 * P * Cin
         return _layer_symbol(tuple(plan[:6])), 2.0 * P * Cin * Cout, byt
+    if name == "pdr_fused_layer_bf16x3":
+        li = args[0]._obj
+        P, Cin, Cout = args[1], args[2], args[6]
+        vid = lib.pdr_fused_layer_variant(li.rows_per_batch, Cout)
+        gath = any(bool(li.seg[s].gV) for s in range(li.n_seg))
+        byt = 4.0 * P * Cout + sum(4.0 * li.seg[s].C * (P // li.seg[s].row_div) for s in range(li.n_seg))
+        if li.rseg.ptr:
+            byt += 4.0 * P * Cin
+        return _layer_symbol((1, vid, bool(li.rseg.ptr), gath, 1, 1)), 2.0 * P * Cin * Cout, byt
     if name == "pdr_gather_add":
         ldu, n_src, B, rpb, K, Cout, Y, ycols = args[1], args[2], args[12], args[13], args[14], args[15], args[16], args[21]
         P = B * rpb
@@ -79,7 +86,7 @@ def _work(name, args, lib):
     return name.replace("pdr_", "") + " (C ABI)", 0.0, 0.0
 
 
-_TIMED = ("pdr_fused_layer", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
+_TIMED = ("pdr_fused_layer", "pdr_fused_layer_bf16x3", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
           "pdr_furthest_point_sampling", "pdr_ball_query", "pdr_knn_points", "pdr_group_build", "pdr_knn_build",
           "pdr_fused_layer_pool", "pdr_knn_weights", "pdr_pad_rows")
 
@@ -146,7 +153,8 @@ def step_kernel_table(sampler, reps=3):
 
 
 def _roof(flops, byt, ms, symbol):
-    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if "bf16x3" in symbol else FP32_MFMA_PEAK_TFLOPS
+    # split mode: three bf16 MFMAs per algorithmic product -> a third of the dense bf16 peak
+    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if symbol.endswith(", true>") else FP32_MFMA_PEAK_TFLOPS
     t_mfma = flops / (peak_tf * 1e12)
     t_hbm = byt / (HBM_PEAK_GBS * 1e9)
     if t_mfma >= t_hbm and flops > 0:
