@@ -19,6 +19,8 @@
 // in-register scan needs only the reference's strict '>'.
 #include "pdr_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kMaxResidentN = 16384;  // 16-bit k / tierank fields
@@ -122,6 +124,203 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(
     old = static_cast<int>(key & 0xFFFFull);
     if (tid == 0) out[j] = old;
   }
+}
+
+// One WAVE per cloud (N <= 64 * PPT <= 2048): no workgroup barrier and no LDS exchange in the round.
+//   * lane l, slot i owns the point of tie rank r = 64 i + l (k = (r % Q) R + bitrev(r / Q)): inside a lane the
+//     slots are already in the reference's tie order, so "first strictly greater wins" needs no sorting;
+//   * the distance update runs on PACKED fp32 (two points per v_pk_* instruction, each half IEEE-exact, the same
+//     SUM3 expression tree -> identical bits);
+//   * the wave arg-max is two 32-bit DPP reductions (value, then rank|index among the lanes holding the value)
+//     instead of one on a 64-bit key; the winner's coordinates come back from LDS by index (one ds_read_b128).
+// A round is ~7 VALU slots per point + ~150 cycles: 2048 -> 1024 in ~0.26 ms (the 4-wave form needs 0.49 ms
+// because every round ends in a barrier + LDS exchange); the deeper levels of the chain shrink likewise.
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+
+// (da, la) <- (db > da) ? (db, lb) : (da, la)
+__device__ __forceinline__ void fps_combine(float& da, unsigned& la, float db, unsigned lb) {
+  asm volatile(
+      "v_cmp_gt_f32 vcc, %2, %0\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %0, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %1, %1, %3, vcc"
+      : "+v"(da), "+v"(la)
+      : "v"(db), "v"(lb)
+      : "vcc");
+}
+// two independent combines, interleaved so that neither mask is read in the two issue slots after its write
+__device__ __forceinline__ void fps_combine2(float& da, unsigned& la, float db, unsigned lb, float& dc,
+                                             unsigned& lc, float dd, unsigned ld) {
+  unsigned long long m;
+  asm volatile(
+      "v_cmp_gt_f32 vcc, %5, %0\n\t"
+      "v_cmp_gt_f32 %4, %7, %2\n\t"
+      "s_nop 0\n\t"
+      "v_cndmask_b32 %0, %0, %5, vcc\n\t"
+      "v_cndmask_b32 %1, %1, %6, vcc\n\t"
+      "v_cndmask_b32 %2, %2, %7, %4\n\t"
+      "v_cndmask_b32 %3, %3, %8, %4"
+      : "+v"(da), "+v"(la), "+v"(dc), "+v"(lc), "=&s"(m)
+      : "v"(db), "v"(lb), "v"(dd), "v"(ld)
+      : "vcc");
+}
+
+// first tree level on two slot pairs (2H, 2H+1) and (2H+2, 2H+3): the slot numbers are immediates
+template <int H>
+__device__ __forceinline__ void fps_first2(const fps_f2& a, const fps_f2& b, float& bd0, unsigned& bs0, float& bd1,
+                                           unsigned& bs1) {
+  unsigned long long m;
+  asm volatile(
+      "v_cmp_gt_f32 vcc, %6, %5\n\t"
+      "v_cmp_gt_f32 %4, %8, %7\n\t"
+      "s_nop 0\n\t"
+      "v_cndmask_b32 %0, %5, %6, vcc\n\t"
+      "v_cndmask_b32 %1, %9, %10, vcc\n\t"
+      "v_cndmask_b32 %2, %7, %8, %4\n\t"
+      "v_cndmask_b32 %3, %11, %12, %4"
+      : "=&v"(bd0), "=&v"(bs0), "=&v"(bd1), "=&v"(bs1), "=&s"(m)
+      : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]), "n"(2 * H), "n"(2 * H + 1), "n"(2 * H + 2), "n"(2 * H + 3)
+      : "vcc");
+}
+template <int H>
+__device__ __forceinline__ void fps_first1(const fps_f2& a, float& bd0, unsigned& bs0) {
+  asm volatile(
+      "v_cmp_gt_f32 vcc, %3, %2\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %0, %2, %3, vcc\n\t"
+      "v_cndmask_b32 %1, %4, %5, vcc"
+      : "=&v"(bd0), "=&v"(bs0)
+      : "v"(a[0]), "v"(a[1]), "n"(2 * H), "n"(2 * H + 1)
+      : "vcc");
+}
+template <int H, int NH>
+__device__ __forceinline__ void fps_level0(const fps_f2 (&tmp)[NH], float (&bd)[NH], unsigned (&bs)[NH]) {
+  if constexpr (H + 1 < NH) {
+    fps_first2<H>(tmp[H], tmp[H + 1], bd[H], bs[H], bd[H + 1], bs[H + 1]);
+    fps_level0<H + 2, NH>(tmp, bd, bs);
+  } else if constexpr (H < NH) {
+    fps_first1<H>(tmp[H], bd[H], bs[H]);
+  }
+}
+
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void fps_wave_kernel(const float* __restrict__ xyz, int N, int m, int R,
+                                                     int Rbits, int Q, int* __restrict__ idxs) {
+  static_assert(PPT % 2 == 0, "points are processed in pairs");
+  constexpr int W = T / 64;
+  extern __shared__ __attribute__((aligned(16))) float4 cloud4[];
+  __shared__ unsigned long long slots[2][W > 1 ? W : 1];   // per-wave (value, rank) of a round, two parities
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;                        // thread index in the workgroup (slot stride = T)
+  const float* p = xyz + static_cast<size_t>(b) * N * 3;
+  int* out = idxs + static_cast<size_t>(b) * m;
+  for (int i = lane; i < N; i += T) cloud4[i] = make_float4(p[i * 3 + 0], p[i * 3 + 1], p[i * 3 + 2], 0.0f);
+
+  // slot i of thread l holds the point of tie rank r = T i + l; only coordinates and running distances stay in
+  // registers -- the slot number is an immediate in the arg-max tree and the point index is recovered from the
+  // winning rank with scalar arithmetic once per round
+  fps_f2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], tmp[PPT / 2];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int r = i * T + lane;
+    const int hi = r / Q, lo = r - hi * Q;
+    const int k = lo * R + static_cast<int>(pdr::bitrev(static_cast<unsigned>(hi), Rbits));
+    const bool valid = hi < R && k < N;
+    const int kk = valid ? k : 0;
+    const float x = p[kk * 3 + 0], y = p[kk * 3 + 1], z = p[kk * 3 + 2];
+    const float mag = PDR_SUM3(x, y, z);
+    // reference: `if (mag <= 1e-3) continue;` -- float promoted to double
+    const float t0 = (!valid || static_cast<double>(mag) <= 1e-3) ? -1.0f : 1e10f;
+    px[i >> 1][i & 1] = valid ? x : 0.0f;
+    py[i >> 1][i & 1] = valid ? y : 0.0f;
+    pz[i >> 1][i & 1] = valid ? z : 0.0f;
+    tmp[i >> 1][i & 1] = t0;                           // padding: never selectable, never updated upward
+  }
+  if (lane == 0) out[0] = 0;
+  __syncthreads();
+
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float4 c = cloud4[old];
+    // ---- phase 1: all distance updates (the results ARE the new running minima).  Written stage by stage over
+    // groups of G pairs so that consecutive instructions are independent: one wave per SIMD has nothing else to
+    // hide the VALU latency of a dependent chain behind
+    constexpr int G = (PPT / 2) < 8 ? (PPT / 2) : 8;
+#pragma unroll
+    for (int h0 = 0; h0 < PPT / 2; h0 += G) {
+      fps_f2 dx[G], dy[G], dz[G], d[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) dy[g] = py[h0 + g] - c.y;
+#pragma unroll
+      for (int g = 0; g < G; ++g) dx[g] = px[h0 + g] - c.x;
+#pragma unroll
+      for (int g = 0; g < G; ++g) d[g] = dy[g] * dy[g];        // PDR_SUM3: fma(c, c, fma(a, a, b * b))
+#pragma unroll
+      for (int g = 0; g < G; ++g) dz[g] = pz[h0 + g] - c.z;
+#pragma unroll
+      for (int g = 0; g < G; ++g) d[g] = __builtin_elementwise_fma(dx[g], dx[g], d[g]);
+#pragma unroll
+      for (int g = 0; g < G; ++g) d[g] = __builtin_elementwise_fma(dz[g], dz[g], d[g]);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        // v_min_f32 directly (fminf / elementwise_min first canonicalise both operands: +1 VALU per point)
+        fps_f2 r;
+        asm("v_min_f32 %0, %1, %2" : "=v"(r[0]) : "v"(d[g][0]), "v"(tmp[h0 + g][0]));
+        asm("v_min_f32 %0, %1, %2" : "=v"(r[1]) : "v"(d[g][1]), "v"(tmp[h0 + g][1]));
+        tmp[h0 + g] = r;
+      }
+    }
+    // ---- phase 2: this lane's arg-max as a TREE over its slots: combine(a, b) with a before b in slot order lets b
+    // win only if STRICTLY greater = "first maximum in slot order", what the sequential strict-'>' scan returns.
+    // The combines are spelled in assembly, two per block (one mask in VCC, one in an SGPR pair, each consumed >= 2
+    // issue slots after it is written): the compiler's own rendering of the select pairs (v_max + v_cmp_eq to
+    // re-derive the winner, an s_nop behind every v_cmp) needed ~900 instructions per round.
+    float bd[PPT / 2];
+    unsigned bs[PPT / 2];                              // winning slot of the sub-tree
+    fps_level0<0, PPT / 2>(tmp, bd, bs);
+#pragma unroll
+    for (int st = 1; st < PPT / 2; st <<= 1) {
+#pragma unroll
+      for (int i = 0; i + st < PPT / 2; i += 4 * st) {
+        if (i + 3 * st < PPT / 2) fps_combine2(bd[i], bs[i], bd[i + st], bs[i + st], bd[i + 2 * st], bs[i + 2 * st],
+                                               bd[i + 3 * st], bs[i + 3 * st]);
+        else fps_combine(bd[i], bs[i], bd[i + st], bs[i + st]);
+      }
+    }
+    const float best = bd[0];
+    // value first (non-negative floats order like their bit patterns; "no candidate" (-1) -> 0), then the tie rank
+    // among the lanes that hold the winning value: smaller rank preferred -> reduce 0xFFFF - r with max
+    const unsigned vb = best < 0.0f ? 0u : __float_as_uint(best);
+    const unsigned vmax = pdr::wave_max_u32(vb);
+    const unsigned rk = 0xFFFFu - (bs[0] * static_cast<unsigned>(T) + static_cast<unsigned>(lane));
+    const unsigned cand = (vb == vmax && best >= 0.0f) ? rk : 0u;
+    unsigned win = pdr::wave_max_u32(cand);            // uniform in the wave
+    if constexpr (W > 1) {
+      // one barrier per round: every wave publishes (value, rank); all read the W entries back
+      unsigned long long* sl = slots[j & 1];
+      if ((lane & 63) == 0) sl[lane >> 6] = pdr::u64_from(vmax, win);
+      __syncthreads();
+      unsigned long long key = sl[0];
+#pragma unroll
+      for (int w = 1; w < W; ++w) {
+        const unsigned long long o = sl[w];
+        key = o > key ? o : key;
+      }
+      win = static_cast<unsigned>(key & 0xFFFFFFFFull);
+    }
+    // rank -> point index with scalar arithmetic (win == 0: no candidate at all -> index 0, as the reference)
+    const int rw = 0xFFFF - static_cast<int>(win);
+    const int hw = rw / Q, lw = rw - hw * Q;
+    old = win == 0u ? 0 : lw * R + static_cast<int>(pdr::bitrev(static_cast<unsigned>(hw), Rbits));
+    if (lane == 0) out[j] = old;
+  }
+}
+
+template <int T, int PPT>
+int launch_wave(const float* xyz, int B, int N, int m, int R, int Rbits, int Q, int* idx, hipStream_t s) {
+  hipLaunchKernelGGL((fps_wave_kernel<T, PPT>), dim3(B), dim3(T), static_cast<size_t>(N) * sizeof(float4), s, xyz, N,
+                     m, R, Rbits, Q, idx);
+  return pdr::check_launch();
 }
 
 // Streaming fallback for N > kMaxResidentN: same ordering rule, running distances
@@ -236,6 +435,32 @@ extern "C" int pdr_furthest_point_sampling(const float* xyz, int B, int N, int m
     hipLaunchKernelGGL(fps_stream_kernel, dim3(B), dim3(1024), 0, s, xyz, N, m, R, Rbits, Q,
                        temp, idx);
     return pdr::check_launch();
+  }
+  // Rank-ordered variant (fps_wave_kernel).  Measured on MI355X, B = 32 (tools/lab/fps_time.py), us per call:
+  //                      2048->1024  1024->256  256->64  3072->1024
+  //   4 waves, barrier        490        105       25        566      (fps_resident_kernel, default above 256 slots)
+  //   1 wave, 32 slots/lane   696        121       20         --      (one wave issues <= 1 instruction / ~4-5 cycles)
+  //   4 waves, rank-ordered   532        127       20        665      (fewer VALU slots, but the round is a LATENCY
+  //                                                                    chain: LDS read -> update -> tree -> 2 DPP
+  //                                                                    reductions -> exchange -> index recovery)
+  // so it is used where it wins (<= 256 slots: no barrier at all).  PDR_FPS_WAVE (process-wide, read once):
+  // 0 = never, 2 = for every size up to 4096 slots (A/B and test runs).
+  static const int wave_mode = []() {
+    const char* e = getenv("PDR_FPS_WAVE");
+    return e ? atoi(e) : 1;
+  }();
+  const bool use_wave = wave_mode == 2 || (wave_mode == 1 && static_cast<long>(R) * Q <= 256);
+  if (use_wave && static_cast<long>(R) * Q <= 4096) {
+    // rank-ordered slots + packed distances + tree arg-max (fps_wave_kernel): ONE wave while a lane holds <= 4
+    // slots (no barrier at all), four waves (one per SIMD: a single wave issues at most one instruction every
+    // ~4-5 cycles, measured 680 ns per round with 32 slots per lane) above that
+    const long slots = static_cast<long>(R) * Q;
+    if (slots <= 128) return launch_wave<64, 2>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (slots <= 256) return launch_wave<64, 4>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (slots <= 512) return launch_wave<256, 2>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (slots <= 1024) return launch_wave<256, 4>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (slots <= 2048) return launch_wave<256, 8>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    return launch_wave<256, 16>(xyz, B, N, m, R, Rbits, Q, idx, s);
   }
   static_assert(kMaxResidentN >= 12288, "resident path must cover the LDS-resident range");
 #define PDR_FPS_CASE(T, PPT) \

@@ -70,6 +70,22 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return u64_from(hi, lo);
 }
 
+// 32-bit form (keys >= 0; lanes without a source read 0 = the identity)
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_step_u32(unsigned v) {
+  const unsigned o = dpp_u32<CTRL>(v);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = dpp_max_step_u32<0x111>(v);
+  v = dpp_max_step_u32<0x112>(v);
+  v = dpp_max_step_u32<0x114>(v);
+  v = dpp_max_step_u32<0x118>(v);
+  v = dpp_max_step_u32<0x142>(v);
+  v = dpp_max_step_u32<0x143>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
