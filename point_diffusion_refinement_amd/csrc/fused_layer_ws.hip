@@ -69,7 +69,12 @@ template <bool SPLIT, int KC, int TM, int TN>
 struct StageMem;
 template <int KC, int TM, int TN>
 struct StageMem<false, KC, TM, TN> {
-  float As[2][KC][TM + 1];
+  // A: channel PAIRS interleaved per row, [k / 2][row][k & 1]: a producer's four consecutive channels of a row
+  // are two ds_write_b64 (k-major fp32 needed four ds_write_b32), a consumer's operand pair one ds_read_b64.
+  // Row padding: 1 (KC = 32: 8 channel quads per 16-lane store group) or 2 (KC = 16: 4 quads) rows make the
+  // 16 lanes of a ds_write_b64 group cover 32 distinct banks; ds_read_b64 of 32 consecutive rows is contiguous.
+  static constexpr int APAD = KC == 32 ? 1 : 2;
+  __attribute__((aligned(8))) float As[2][KC / 2][TM + APAD][2];
   __attribute__((aligned(16))) float Bs[2][KC][TN];
 };
 template <int KC, int TM, int TN>
@@ -365,8 +370,11 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             if constexpr (ADD) v = v + Rpa[j];
             if constexpr (RADD) v = v + q[j];
             if constexpr (MASKED) v = j < Rcvalid ? v : 0.0f;
-            if constexpr (SPLIT) x[j] = v;
-            else sm.As[st][4 * vc4 + j][vr0 + VSTEP * i] = v;
+            x[j] = v;
+          }
+          if constexpr (!SPLIT) {
+            *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4][vr0 + VSTEP * i][0]) = f32x2{x[0], x[1]};
+            *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4 + 1][vr0 + VSTEP * i][0]) = f32x2{x[2], x[3]};
           }
           if constexpr (SPLIT) {
             // x = hi + lo + O(2^-17 |x|): hi = bf16(x) (round to nearest even), lo = bf16(x - hi); the four
@@ -484,18 +492,27 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           }
       }
     } else {
-      const int ksteps = (min(KC, in.seg[cur.sg].C - cur.ks) + 1) >> 1;
-      for (int kk = 0; kk < ksteps; ++kk) {
-        float a[RT], w[CT];
+      // four channels per iteration = two MFMAs: lane half `hi` holds channels 4 kq + 2 hi (first MFMA) and
+      // 4 kq + 2 hi + 1 (second), i.e. the pair it read with ONE ds_read_b64; channels >= kmax are zero in A
+      const int kquads = (min(KC, in.seg[cur.sg].C - cur.ks) + 3) >> 2;
+      for (int kq = 0; kq < kquads; ++kq) {
+        f32x2 a[RT];
+        float w0[CT], w1[CT];
 #pragma unroll
-        for (int i = 0; i < RT; ++i) a[i] = sm.As[st][2 * kk + hi][(wr * RT + i) * 32 + il];
+        for (int i = 0; i < RT; ++i)
+          a[i] = *reinterpret_cast<const f32x2*>(&sm.As[st][2 * kq + hi][(wr * RT + i) * 32 + il][0]);
 #pragma unroll
-        for (int j = 0; j < CT; ++j) w[j] = sm.Bs[st][2 * kk + hi][(wc * CT + j) * 32 + il];
+        for (int j = 0; j < CT; ++j) {
+          w0[j] = sm.Bs[st][4 * kq + 2 * hi][(wc * CT + j) * 32 + il];
+          w1[j] = sm.Bs[st][4 * kq + 2 * hi + 1][(wc * CT + j) * 32 + il];
+        }
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
-          for (int j = 0; j < CT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], w[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < CT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, w0[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, w1[j], acc[i][j], 0, 0, 0);
+          }
       }
     }
     PDR_T(0, 4 * g + 2);
