@@ -22,8 +22,14 @@
  *     zero-initialised: every output element is written by the kernel.
  *   - return value: PDR_OK (0) or a negative PDR_E* code.  Nothing prints or
  *     calls exit() (contrast cuda_utils.h:30-39).  No hidden allocation, no
- *     device synchronisation, no global state: calls are thread-safe and
- *     capturable into a hipGraph.
+ *     device synchronisation, no mutable global state: calls are thread-safe and
+ *     capturable into a hipGraph.  The only process-wide inputs are two tuning
+ *     knobs read ONCE from the environment (kernel selection only, results are
+ *     identical): PDR_FUSED_WS=0 (uniform-wave layer kernels) and PDR_FPS_WAVE=0|2
+ *     (furthest-point-sampling kernel family, see pdr_furthest_point_sampling).
+ *   - validation covers pointers, sizes and alignment; VALUES are not inspected
+ *     (an out-of-range index in a caller-provided idx array is undefined
+ *     behaviour, as in the reference's kernels).
  *   - int32 indexing: B*C*N*nsample must stay below 2^31 (same as reference).
  */
 #ifndef PDR_HIP_H

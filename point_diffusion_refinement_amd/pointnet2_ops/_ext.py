@@ -29,6 +29,12 @@ def _req(t, name, dtype):
         raise RuntimeError("%s must be a %s tensor" % (name, "float" if dtype == torch.float32 else "int"))
 
 
+def _req_xyz(t, name):
+    """(B, N, 3) coordinate clouds: the kernels read three floats per point."""
+    if t.dim() != 3 or t.shape[2] != 3:
+        raise RuntimeError("%s must have shape (B, N, 3), got %s" % (name, tuple(t.shape)))
+
+
 def _same_device(*ts):
     d = ts[0].device
     for t in ts[1:]:
@@ -39,6 +45,7 @@ def _same_device(*ts):
 def furthest_point_sampling(points, nsamples):
     """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:66-87]"""
     _req(points, "points", torch.float32)
+    _req_xyz(points, "points")
     B, N, _ = points.shape
     lib = _lib.load()
     out = torch.empty((B, nsamples), dtype=torch.int32, device=points.device)
@@ -82,7 +89,11 @@ def ball_query(new_xyz, xyz, radius, nsample):
     """(B,m,3), (B,n,3), r, ns -> (idx (B,m,ns) i32, counts (B,m) i32)   [ball_query.cpp:10-38]"""
     _req(new_xyz, "new_xyz", torch.float32)
     _req(xyz, "xyz", torch.float32)
+    _req_xyz(new_xyz, "new_xyz")
+    _req_xyz(xyz, "xyz")
     _same_device(new_xyz, xyz)
+    if new_xyz.shape[0] != xyz.shape[0]:
+        raise RuntimeError("new_xyz and xyz must have the same batch size")
     B, m, _ = new_xyz.shape
     n = xyz.shape[1]
     idx = torch.empty((B, m, nsample), dtype=torch.int32, device=xyz.device)
@@ -125,6 +136,8 @@ def three_nn(unknowns, knows):
     """(B,n,3), (B,m,3) -> [dist2 (B,n,3) f32 SQUARED, idx (B,n,3) i32]   [interpolate.cpp:14-40]"""
     _req(unknowns, "unknowns", torch.float32)
     _req(knows, "knows", torch.float32)
+    _req_xyz(unknowns, "unknowns")
+    _req_xyz(knows, "knows")
     _same_device(unknowns, knows)
     B, n, _ = unknowns.shape
     m = knows.shape[1]
