@@ -43,7 +43,7 @@ def _layer_symbol(plan):
     ws, vid, radd, gath, vec, split = plan
     t = ", ".join(str(v) for v in _VARIANT[vid])
     if ws:
-        return "fused_layer_ws_kernel<%s, %s, %s%s>" % (t, _b(radd), _b(gath), ", true" if split else "")
+        return "fused_layer_ws_kernel<%s, %s, %s, %s>" % (t, _b(radd), _b(gath), _b(split))
     return "fused_layer_kernel<%s, %s, %s, %s, false>" % (t, _b(radd), _b(vec), _b(gath))
 
 

@@ -113,6 +113,12 @@ def main():
         row = {"kernel": k, "launches": n, "avg_us_under_pmc": round(dur / 1e3, 2),
                "mfma_busy_cycles_per_launch": round(busy),
                "mfma_util": round(busy / (dur * 1e-9 * CLOCK_HZ * SIMDS), 4) if dur > 0 else None}
+        cu = v["SQ_BUSY_CU_CYCLES"][0] / max(v["SQ_BUSY_CU_CYCLES"][1], 1)
+        if cu > 0:
+            # SQ_BUSY_CU_CYCLES sums the busy cycles of the 256 CUs: busy / (4 SIMDs x that) is the matrix-pipe
+            # utilisation in ACTUAL shader cycles, and cu / 256 / duration the clock the kernel really ran at
+            row["mfma_util_of_busy_cu_cycles"] = round(busy / (4.0 * cu), 4)
+            row["implied_clock_GHz"] = round(cu / 256.0 / dur, 3) if dur > 0 else None
         wc = v["SQ_WAVE_CYCLES"][0] / max(v["SQ_WAVE_CYCLES"][1], 1)
         if wc > 0:
             row["issue_stalled_frac_of_wave_cycles"] = round(v["SQ_WAIT_INST_ANY"][0] / max(v["SQ_WAIT_INST_ANY"][1], 1) / wc, 3)
@@ -120,7 +126,9 @@ def main():
         mfma.append(row)
     mfma.sort(key=lambda r: -r["mfma_busy_cycles_per_launch"] * r["launches"])
     json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs); the fp32 "
-                       "MFMA peak (157.3 TF) corresponds to 1.0",
+                       "MFMA peak (157.3 TF) corresponds to 1.0.  mfma_util_of_busy_cu_cycles normalises by the "
+                       "cycles the CUs actually ran (SQ_BUSY_CU_CYCLES): the gap between the two is the clock "
+                       "the chip sustains under this load (implied_clock_GHz), not pipeline inefficiency",
                "kernels": mfma[:60]}, open(os.path.join(out, tag + "_mfma_util.json"), "w"), indent=1)
     # ---- roofline table
     tmap = {r["kernel"]: r for r in traffic}
