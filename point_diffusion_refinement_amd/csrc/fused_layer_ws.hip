@@ -315,11 +315,27 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
                         : static_cast<unsigned>(min(k, Rkmax - 1) * ldw + min(4 * n4, nmax)) * 4u;
         }
       }
+      if (Rkmax == KC) {
+        // full chunk (uniform): this thread's four channels are consecutive and all valid -> the prologue
+        // parameters are three 16-byte loads (4-byte aligned in general: dwordx4 tolerates that) instead of twelve
+        // dword loads -- 20 -> 11 VMEM instructions per chunk and thread
+        f32x4 s4, h4, a4;
+        __builtin_memcpy(&s4, reinterpret_cast<const char*>(sc_b) + 16u * vc4, 16);
+        __builtin_memcpy(&h4, reinterpret_cast<const char*>(sh_b) + 16u * vc4, 16);
+        __builtin_memcpy(&a4, reinterpret_cast<const char*>(ad_b) + 16u * vc4, 16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        Rps[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sc_b) + po[j]);
-        Rph[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sh_b) + po[j]);
-        Rpa[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ad_b) + po[j]);
+        for (int j = 0; j < 4; ++j) {
+          Rps[j] = s4[j];
+          Rph[j] = h4[j];
+          Rpa[j] = a4[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Rps[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sc_b) + po[j]);
+          Rph[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sh_b) + po[j]);
+          Rpa[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ad_b) + po[j]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < APT4; ++i) Rrv[i] = *reinterpret_cast<const float4*>(ab + ao[i]);

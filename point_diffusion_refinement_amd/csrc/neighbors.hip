@@ -222,6 +222,10 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ xa, 
   }
 }
 
+#ifndef PDR_NN1_QP
+#define PDR_NN1_QP 2     // query PAIRS per thread of the K = 1 kernel (lab builds: -DPDR_NN1_QP=4)
+#endif
+
 template <int K>
 int launch_knn(const float* x, const float* y, int B, int n1, int n2, int Kout, float* dists,
                int64_t* idx, float* nn, hipStream_t s) {
@@ -254,8 +258,9 @@ extern "C" int pdr_knn_points(const float* x, const float* y, int B, int n1, int
   hipStream_t s = pdr::as_stream(stream);
   if (K == 1 && !nn && n2 > 0) {
     // dedicated packed-math kernel (one direction of pdr_chamfer_nn); bit-identical results
-    hipLaunchKernelGGL((nn1_kernel<2, int64_t>), dim3((n1 + 1023) / 1024, B, 1), dim3(256), 0, s, x, y, n1, n2,
-                       dists, idx, static_cast<float*>(nullptr), static_cast<int64_t*>(nullptr));
+    constexpr int QPB = 256 * 2 * PDR_NN1_QP;   // queries per workgroup
+    hipLaunchKernelGGL((nn1_kernel<PDR_NN1_QP, int64_t>), dim3((n1 + QPB - 1) / QPB, B, 1), dim3(256), 0, s, x, y, n1,
+                       n2, dists, idx, static_cast<float*>(nullptr), static_cast<int64_t*>(nullptr));
     return pdr::check_launch();
   }
   if (K == 1) return launch_knn<1>(x, y, B, n1, n2, K, dists, idx, nn, s);
@@ -274,7 +279,8 @@ extern "C" int pdr_chamfer_nn(const float* x, const float* y, int B, int n1, int
   if (B == 0) return PDR_OK;
   if (!x || !y || !dist_xy || !idx_xy || !dist_yx || !idx_yx) return PDR_EINVAL;
   const int nmax = n1 > n2 ? n1 : n2;
-  hipLaunchKernelGGL((nn1_kernel<2, int64_t>), dim3((nmax + 1023) / 1024, B, 2), dim3(256), 0,
+  constexpr int QPB = 256 * 2 * PDR_NN1_QP;
+  hipLaunchKernelGGL((nn1_kernel<PDR_NN1_QP, int64_t>), dim3((nmax + QPB - 1) / QPB, B, 2), dim3(256), 0,
                      pdr::as_stream(stream), x, y, n1, n2, dist_xy, idx_xy, dist_yx, idx_yx);
   return pdr::check_launch();
 }
