@@ -369,6 +369,9 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     float* __restrict__ partial, int relu_col0, int ycol0, int ycol1) {
   constexpr int TM = 128;
   constexpr int RPI = 64 / LPR;            // rows per wave instruction
+  // row groups in flight per iteration: the kernel is bound by the latency of its L2 gathers, so every wave keeps
+  // DEPTH x 2 independent 16-byte loads outstanding (4 measured against 2: see DESIGN.md)
+  constexpr int DEPTH = 32 / RPI < 4 ? 32 / RPI : 4;
   constexpr int CW = 4 * LPR;              // columns covered per pass
   __shared__ float red[4][CW][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -396,12 +399,12 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     if (cok && r1) q1 = *reinterpret_cast<const float4*>(r1 + c);
     if (cok && r2) q2 = *reinterpret_cast<const float4*>(r2 + c);
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (int r = 0; r < nrows; r += 2 * RPI) {
-      float4 u[2], v[2];
-      float t1[2], t2[2];
-      int em[2], rr[2];
+    for (int r = 0; r < nrows; r += DEPTH * RPI) {
+      float4 u[DEPTH], v[DEPTH];
+      float t1[DEPTH], t2[DEPTH];
+      int em[DEPTH], rr[DEPTH];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < DEPTH; ++k) {
         rr[k] = r + k * RPI + sub;                               // this lane's row (per sub-group)
         const int rc = min(rr[k], nrows - 1);
         const int a = __shfl(my_idx, rc, 64);
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
         v[k] = *reinterpret_cast<const float4*>((em[k] ? V0 : V) + q * ldv + cc);
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < DEPTH; ++k) {
         if (rr[k] < nrows && cok) {
           float4 y;
           if (em[k]) {
