@@ -205,6 +205,38 @@ class Conv:
         self.widths = [w.shape[0] for w in ws]
 
 
+# Every grouped block evaluates its two independent halves -- shared MLP + value conv | query conv + score convs --
+# on two streams between the first GEMM and the pooling (parallel branches of the captured hipGraph).
+# `_PAR["stream"]` is set by the network around its forward.  Measured on MI355X (B = 32, same box, ms per step):
+# off 11.08 / 11.14, blocks of <= 65,536 positions 11.05 / 11.03, <= 1 M positions 10.94 / 10.94, all blocks
+# 10.89 / 10.88 (B = 8: 5.61 -> 5.30 with the deep levels alone): the small launches of one half fill the gaps and
+# tails of the other, also at level 0.  PDR_PAR_DEEP=0 turns it off, PDR_PAR_MAX_ROWS bounds it (A/B).
+_PAR = {"stream": None}
+PAR_DEEP = __import__("os").environ.get("PDR_PAR_DEEP", "1") == "1"
+PAR_MAX_ROWS = int(__import__("os").environ.get("PDR_PAR_MAX_ROWS", str(1 << 40)))
+
+
+def _fork_join(rows, chain_a):
+    """Run `chain_a()` on the auxiliary stream if this block qualifies; returns a thunk that joins and yields its
+    result (or the result itself when everything stays on the current stream)."""
+    aux = _PAR["stream"]
+    if aux is None or rows > PAR_MAX_ROWS:
+        return chain_a()
+    main = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(main)
+    aux.wait_event(fork)
+    with torch.cuda.stream(aux):
+        result = chain_a()
+        done = torch.cuda.Event()
+        done.record(aux)
+
+    def join():
+        main.wait_event(done)
+        return result
+    return join
+
+
 # Arithmetic of the wide GEMMs of the forward in flight: "f32" (exact fp32 MFMA, default) or "split_bf16"
 # (opt-in; FusedCloudConditionNet(precision=...) sets it around its forward).  See pack_bf16x3 / run_layer.
 _PRECISION = ["f32"]
@@ -521,7 +553,8 @@ class FusedAttention:
             S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
-        V, vs, vt = values if values is not None else self.values(h, B, npoint, K)
+        # (a callable: the value half runs on another stream; calling it joins that stream into this one)
+        V, vs, vt = values() if callable(values) else (values if values is not None else self.values(h, B, npoint, K))
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
         cptr = counts.data_ptr() if counts is not None else None
         vsp, vtp = (vs.data_ptr(), vt.data_ptr()) if vs is not None else (None, None)
@@ -751,7 +784,26 @@ class FusedGroupedBlock:
         return out.view(B, m, -1)
 
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
-        return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh, V2=V2), query_feats_cl)
+        B, m, _ = new_xyz.shape
+        K = self.nsample
+        if not (USE_SPLIT_FIRST and _PAR["stream"] is not None and B * m * K <= PAR_MAX_ROWS):
+            return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh, V2=V2),
+                               query_feats_cl)
+        # deep level: first GEMM here, then [MLP + value conv] on the auxiliary stream beside [query / score convs]
+        idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
+        split = self._make_split(src_feats_cl.shape[2])
+        Y1, part1, tpb1 = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
+                                self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
+                                res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
+                                U=self.static_U, V2=V2)
+
+        def chain_a():
+            h, _, _, _ = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
+            return self.att.values(h, B, m, K)
+        values = _fork_join(B * m * K, chain_a)
+        out = self.att(query_feats_cl.reshape(B * m, -1), None, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K,
+                       values=values)
+        return out.view(B, m, -1)
 
 
 class FusedKnnFP:
@@ -778,7 +830,14 @@ class FusedKnnFP:
                 self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
             Y1, part1, tpb1 = self.split(known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0,
                                          s1=d2, s2=wgt)
-            h, Y1, part1, tpb1 = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
+            if _PAR["stream"] is not None and B * n * K <= PAR_MAX_ROWS:
+                def chain_a():
+                    hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
+                    return self.att.values(hh, B, n, K)
+                h, values = None, _fork_join(B * n * K, chain_a)
+            else:
+                h, Y1, part1, tpb1 = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
+                values = None
         else:
             G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
             idx64 = idx.long()
@@ -786,8 +845,9 @@ class FusedKnnFP:
                                          idx64.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
                                          _stream()), "knn_build")
             h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
+            values = None
         interp = self.att(unknown_feats_cl.reshape(B * n, -1), h, Y1, part1, tpb1, self.mlp1.extra_col0, None, B, n,
-                          K)
+                          K, values=values)
         Cs = unknown_feats_cl.shape[2]
         x2 = Act([(interp, 0, self.att.D, interp.shape[1], 1),
                   (xyz4(unknown_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(unknown), 0, 3, 4, 1)], B * n, B, n)
@@ -924,6 +984,8 @@ class FusedCloudConditionNet:
                            use_retained_condition_feature=use_retained_condition_feature)
         saved = _PRECISION[0]
         _PRECISION[0] = self.precision
+        saved_par = _PAR["stream"]
+        _PAR["stream"] = self._aux_stream() if PAR_DEEP else None
         try:
             if fresh:
                 _XYZ4.clear()
@@ -931,6 +993,7 @@ class FusedCloudConditionNet:
             return self._forward_cached(pointcloud, condition, ts, label)
         finally:
             _PRECISION[0] = saved
+            _PAR["stream"] = saved_par
             if not use_retained_condition_feature:
                 self.reset_cond_features()
 
