@@ -211,6 +211,11 @@ class Conv:
 # off 11.08 / 11.14, blocks of <= 65,536 positions 11.05 / 11.03, <= 1 M positions 10.94 / 10.94, all blocks
 # 10.89 / 10.88 (B = 8: 5.61 -> 5.30 with the deep levels alone): the small launches of one half fill the gaps and
 # tails of the other, also at level 0.  PDR_PAR_DEEP=0 turns it off, PDR_PAR_MAX_ROWS bounds it (A/B).
+# Per-query first-conv tables ([V | V0]: coordinates x static weights) of every block but the first CAN be evaluated
+# on the geometry stream right after the last ball query (~2 small GEMMs + a pad per block leave the main stream).
+# Measured on MI355X (B = 32, same box): 10.85 / 10.91 ms per step vs 10.87 / 10.87 inside the blocks (B = 8: 5.20 vs
+# 5.17) -- no gain once the blocks run their halves on two streams -- so it is OFF; PDR_SIDE_TABLES=1 enables it.
+SIDE_TABLES = __import__("os").environ.get("PDR_SIDE_TABLES", "0") == "1"
 _PAR = {"stream": None}
 PAR_DEEP = __import__("os").environ.get("PDR_PAR_DEEP", "1") == "1"
 PAR_MAX_ROWS = int(__import__("os").environ.get("PDR_PAR_MAX_ROWS", str(1 << 40)))
@@ -817,7 +822,7 @@ class FusedKnnFP:
         self.mlp2 = FusedMlp(fp.mlp2, bank)
         self.split = None
 
-    def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank, knn=None):
+    def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank, knn=None, V2=None):
         lib = _lib.load()
         B, n, _ = unknown.shape
         n2, C = known.shape[1], known_feats_cl.shape[2]
@@ -829,7 +834,7 @@ class FusedKnnFP:
             if self.split is None:
                 self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
             Y1, part1, tpb1 = self.split(known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0,
-                                         s1=d2, s2=wgt)
+                                         s1=d2, s2=wgt, V2=V2)
             if _PAR["stream"] is not None and B * n * K <= PAR_MAX_ROWS:
                 def chain_a():
                     hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
@@ -1051,6 +1056,9 @@ class FusedCloudConditionNet:
         # (shipped configs): that ball query is computed once and shared.
         main = torch.cuda.current_stream()
         side = self._side_stream()
+        # the 16-byte padded level-0 coordinates are read by both streams: produce them HERE, ordered before the fork
+        # (the cache would otherwise hand the main stream a copy the side stream is still writing)
+        xyz4(xyz)
         side.wait_stream(main)
         nlev = len(self.sa)
         l_xyz, sels, fm_neigh, sa_neigh, knn = [xyz], [], {}, [], {}
@@ -1081,6 +1089,22 @@ class FusedCloudConditionNet:
                     xyz4(t)
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
+            tables, ev_tables = {}, None
+            if SIDE_TABLES and USE_SPLIT_FIRST:
+                # (a block's SplitFirstConv exists from its first evaluation on; the eager first step of a batch
+                # therefore computes the tables inline, every captured step here)
+                for i in range(nlev + 1):
+                    for blk in ([self.enc_map[i]] if 0 < i < nlev else []) + [self.dec_map[i]]:
+                        if blk.split is not None:
+                            tables[id(blk)] = blk.split.query_tables(l_xyz[i], has_v0=True)
+                for i, sa in enumerate(self.sa):
+                    if sa.split is not None:
+                        tables[id(sa)] = sa.split.query_tables(l_xyz[i + 1], has_v0=False)
+                for i in range(-1, -(len(self.fp) + 1), -1):
+                    if self.fp[i].split is not None:
+                        tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
+                ev_tables = torch.cuda.Event()
+                ev_tables.record(side)
             for i in range(-1, -(len(self.fp) + 1), -1):
                 knn[i] = _ext.knn_group(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
             ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
@@ -1095,7 +1119,9 @@ class FusedCloudConditionNet:
         if AHEAD_LEVEL <= nlev:
             ev_bank = torch.cuda.Event()
             ev_bank.record(main)
-            aux = self._aux_stream()
+            if getattr(self, "_ahead", None) is None:
+                self._ahead = torch.cuda.Stream(device=next(self.net.parameters()).device)
+            aux = self._ahead               # its own stream: the blocks fork their halves onto _aux_stream()
             aux.wait_event(ev_all)
             aux.wait_event(ev_bank)
             todo = [(self.enc_map[l], l, enc_cl) for l in range(AHEAD_LEVEL, nlev)] + \
@@ -1118,18 +1144,23 @@ class FusedCloudConditionNet:
         main.wait_event(ev_first)
         l_feat = [feat0]
         for i, sa in enumerate(self.sa):
-            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=v2_first if i == 0 else None)
+            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i],
+                              V2=v2_first if i == 0 else tables.get(id(self.enc_map[i])))
             if i == 0:
                 main.wait_event(ev_all)
+                if ev_tables is not None:
+                    main.wait_event(ev_tables)
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)
             centre = gather_rows(sa_in, sels[i])
-            l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i]))
+            l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i],
+                             V2=tables.get(id(sa))))
         main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
-            mapped = transfer(self.dec_map[i], i % (nlev + 1), dec_cl, l_feat[i])
+            mapped = transfer(self.dec_map[i], i % (nlev + 1), dec_cl, l_feat[i], V2=tables.get(id(self.dec_map[i])))
             fp_in = torch.cat([mapped, l_feat[i]], dim=2)
-            l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i])
-        mapped = transfer(self.dec_map[0], 0, dec_cl, l_feat[0])
+            l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i],
+                                       V2=tables.get(id(self.fp[i])))
+        mapped = transfer(self.dec_map[0], 0, dec_cl, l_feat[0], V2=tables.get(id(self.dec_map[0])))
         assert not ahead
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz4(xyz), 0, 3, 4, 1)], B * N, B, N)
