@@ -360,7 +360,7 @@ extern "C" int pdr_gather_rows(const float* src, const int* idx, int B, int n, i
 // registers.  A row is covered by LPR lanes x float4 (LPR = 16 / 32 / 64 by output width), so a wave
 // instruction moves 64 / LPR rows and narrow outputs keep every lane busy; two row groups are in
 // flight per iteration.  Every U / V / Y access is a contiguous row segment.
-template <int LPR>
+template <int LPR, bool KPOW2, bool HAS_S>
 __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ U, int ldu, int n_src, const float* __restrict__ V,
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
@@ -391,6 +391,17 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
   const float my_s2 = s2 ? s2[myp] : 0.0f;
   const int nrows = max(0, min(32, nvalid - wr0));   // uniform
 
+  // The kernel is VALU-issue bound (PMC: 35 VALU instructions per 16-byte gather before this rewrite, waves
+  // issue-stalled 47 % of their cycles), so the per-row work is kept minimal: the query row is an add + shift when
+  // K is a power of two that divides the wave's 32 rows (every shipped config; the general form is a 64-bit
+  // division per row group), the kNN terms and the empty-ball select exist only where their inputs do (uniform
+  // branches), the ReLU of the statistics is one v_max against a per-lane bound, addresses are 32-bit offsets.
+  constexpr bool has_s = HAS_S;                            // kNN terms d2 r1 + w r2 present
+  const bool has_em = counts != nullptr;                  // uniform
+  const int ksh = KPOW2 ? __builtin_ctz(K) : -1;          // KPOW2: K a power of two <= 32
+  const long qbase = (row0 + wr0) / K;                     // exact when ksh >= 0 (row0 + wr0 is a multiple of K)
+  const float* Vq = V + qbase * ldv;
+  const long v0d = has_em ? V0 - V : 0;                    // elements from V to V0 (same address space)
   for (int c0 = 0; c0 < Cout; c0 += CW) {
     const int c = c0 + 4 * cl;
     const bool cok = c < Cout;   // row widths are padded to a multiple of 4 in ldu / ldv / ldy
@@ -398,6 +409,10 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     float4 q1 = make_float4(0, 0, 0, 0), q2 = make_float4(0, 0, 0, 0);
     if (cok && r1) q1 = *reinterpret_cast<const float4*>(r1 + c);
     if (cok && r2) q2 = *reinterpret_cast<const float4*>(r2 + c);
+    float lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] = (c + j >= relu_col0) ? 0.0f : -__builtin_inff();
+    const bool ywin = Y && c >= ycol0 && c < ycol1;
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
     for (int r = 0; r < nrows; r += DEPTH * RPI) {
       float4 u[DEPTH], v[DEPTH];
@@ -408,12 +423,16 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
         rr[k] = r + k * RPI + sub;                               // this lane's row (per sub-group)
         const int rc = min(rr[k], nrows - 1);
         const int a = __shfl(my_idx, rc, 64);
-        em[k] = __shfl(my_empty, rc, 64);
-        t1[k] = __shfl(my_s1, rc, 64);
-        t2[k] = __shfl(my_s2, rc, 64);
-        const long q = (row0 + wr0 + rc) / K;
-        u[k] = *reinterpret_cast<const float4*>(Ub + static_cast<long>(a) * ldu + cc);
-        v[k] = *reinterpret_cast<const float4*>((em[k] ? V0 : V) + q * ldv + cc);
+        em[k] = has_em ? __shfl(my_empty, rc, 64) : 0;
+        if (has_s) {
+          t1[k] = __shfl(my_s1, rc, 64);
+          t2[k] = __shfl(my_s2, rc, 64);
+        }
+        u[k] = *reinterpret_cast<const float4*>(Ub + static_cast<unsigned>(a * ldu + cc));
+        const float* vp;
+        if constexpr (KPOW2) vp = Vq + static_cast<unsigned>((rc >> ksh) * ldv + cc);
+        else vp = V + ((row0 + wr0 + rc) / K) * ldv + cc;
+        v[k] = *reinterpret_cast<const float4*>(vp + (em[k] ? v0d : 0));
       }
 #pragma unroll
       for (int k = 0; k < DEPTH; ++k) {
@@ -423,17 +442,19 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
             y = v[k];
           } else {
             y = make_float4(u[k].x + v[k].x, u[k].y + v[k].y, u[k].z + v[k].z, u[k].w + v[k].w);
-            y.x = __builtin_fmaf(t1[k], q1.x, y.x); y.y = __builtin_fmaf(t1[k], q1.y, y.y);
-            y.z = __builtin_fmaf(t1[k], q1.z, y.z); y.w = __builtin_fmaf(t1[k], q1.w, y.w);
-            y.x = __builtin_fmaf(t2[k], q2.x, y.x); y.y = __builtin_fmaf(t2[k], q2.y, y.y);
-            y.z = __builtin_fmaf(t2[k], q2.z, y.z); y.w = __builtin_fmaf(t2[k], q2.w, y.w);
+            if (has_s) {
+              y.x = __builtin_fmaf(t1[k], q1.x, y.x); y.y = __builtin_fmaf(t1[k], q1.y, y.y);
+              y.z = __builtin_fmaf(t1[k], q1.z, y.z); y.w = __builtin_fmaf(t1[k], q1.w, y.w);
+              y.x = __builtin_fmaf(t2[k], q2.x, y.x); y.y = __builtin_fmaf(t2[k], q2.y, y.y);
+              y.z = __builtin_fmaf(t2[k], q2.z, y.z); y.w = __builtin_fmaf(t2[k], q2.w, y.w);
+            }
           }
-          if (Y && c >= ycol0 && c < ycol1)
-            *reinterpret_cast<float4*>(Y + (row0 + wr0 + rr[k]) * ldy + (c - ycol0)) = y;
+          if (ywin) *reinterpret_cast<float4*>(Y + (row0 + wr0 + rr[k]) * ldy + (c - ycol0)) = y;
           const float e[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float f = (c + j >= relu_col0) ? fmaxf(e[j], 0.0f) : e[j];
+            float f;
+            asm("v_max_f32 %0, %1, %2" : "=v"(f) : "v"(e[j]), "v"(lo[j]));   // max(y, 0) or y (bound -inf)
             a1[j] += f;
             a2[j] = __builtin_fmaf(f, f, a2[j]);
           }
@@ -499,13 +520,23 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
   const int tpb = (rows_per_batch + 127) / 128;
   const dim3 grid(static_cast<unsigned>(B) * tpb);
   hipStream_t st = pdr::as_stream(stream);
-#define PDR_GA(LPR)                                                                                   \
-  hipLaunchKernelGGL(gather_add_kernel<LPR>, grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
+  const bool kpow2 = (K & (K - 1)) == 0 && K <= 32;
+  const bool has_s = s1 != nullptr || s2 != nullptr;
+#define PDR_GA_K(LPR, KP, HS)                                                                          \
+  hipLaunchKernelGGL((gather_add_kernel<LPR, KP, HS>), grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
                      counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0, ycol0, \
                      ycol0 + y4)
+#define PDR_GA(LPR)                                       \
+  do {                                                    \
+    if (kpow2 && has_s) PDR_GA_K(LPR, true, true);        \
+    else if (kpow2) PDR_GA_K(LPR, true, false);           \
+    else if (has_s) PDR_GA_K(LPR, false, true);           \
+    else PDR_GA_K(LPR, false, false);                     \
+  } while (0)
   if (Cout <= 64) PDR_GA(16);
   else if (Cout <= 128) PDR_GA(32);
   else PDR_GA(64);
 #undef PDR_GA
+#undef PDR_GA_K
   return pdr::check_launch();
 }
