@@ -24,7 +24,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc/$c -o p -- $BENCH --steps 2 > $OUT/${TAG}_pmc.$c.log 2>&1
   tail -1 $OUT/${TAG}_pmc.$c.log | cut -c1-120
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD \
   --output-format csv -d $OUT/${TAG}_pmc/SQ -o p -- $BENCH --steps 2 > $OUT/${TAG}_pmc.SQ.log 2>&1
 tail -1 $OUT/${TAG}_pmc.SQ.log | cut -c1-120
 cd $REPO

@@ -89,7 +89,8 @@ def main():
     fetch = counters(os.path.join(pmc, "FETCH_SIZE"), ["FETCH_SIZE"])
     write = counters(os.path.join(pmc, "WRITE_SIZE"), ["WRITE_SIZE"])
     sq = counters(os.path.join(pmc, "SQ"), ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES",
-                                            "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])
+                                            "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU",
+                                            "SQ_INSTS_VMEM_RD"])
     traffic = []
     for k, v in fetch.items():
         n = v["FETCH_SIZE"][1]
@@ -123,6 +124,14 @@ def main():
         if wc > 0:
             row["issue_stalled_frac_of_wave_cycles"] = round(v["SQ_WAIT_INST_ANY"][0] / max(v["SQ_WAIT_INST_ANY"][1], 1) / wc, 3)
             row["active_frac_of_wave_cycles"] = round(v["SQ_ACTIVE_INST_ANY"][0] / max(v["SQ_ACTIVE_INST_ANY"][1], 1) / wc, 3)
+            row["parked_frac_of_wave_cycles"] = round(v["SQ_WAIT_ANY"][0] / max(v["SQ_WAIT_ANY"][1], 1) / wc, 3)
+        nv = v["SQ_INSTS_VALU"][0] / max(v["SQ_INSTS_VALU"][1], 1)
+        nm = v["SQ_INSTS_VMEM_RD"][0] / max(v["SQ_INSTS_VMEM_RD"][1], 1)
+        if nv > 0:
+            # wave-level instruction counts per launch: VALU issue time = 2 cycles each on a SIMD-32
+            row["valu_insts_per_launch"] = round(nv)
+            row["vmem_rd_insts_per_launch"] = round(nm)
+            row["valu_issue_us_at_2p1GHz"] = round(nv * 2.0 / SIMDS / 2.1e9 * 1e6, 1)
         mfma.append(row)
     mfma.sort(key=lambda r: -r["mfma_busy_cycles_per_launch"] * r["launches"])
     json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs); the fp32 "
