@@ -103,11 +103,11 @@ def test_config5_fastdpm_refine_upsample_chamfer_full_size(cuda):
     coarse = (got / got.abs().amax(dim=(1, 2), keepdim=True)).contiguous()
     with torch.no_grad():
         rnet.reset_cond_features()
-        disp_ref = rnet(coarse, cond, ts=None, label=label)                      # (B, 2048, 24) displacement
+        disp_ref = rnet(coarse, cond, ts=None, label=label)                      # (B, 2048, 3 (f + 1)) displacement
         disp = rfused(coarse, cond, ts=None, label=label)
         fine_ref = G.refine_completion(rnet, coarse, cond, label, 0.001, 8)
         fine = G.refine_completion(rfused, coarse, cond, label, 0.001, 8)
-    assert disp.shape == disp_ref.shape == (B, 2048, 24)
+    assert disp.shape == disp_ref.shape == (B, 2048, 3 * (8 + 1))               # centre + 8 offsets per point
     assert fine.shape == (B, 16384, 3) and fine_ref.shape == (B, 16384, 3)
     err = (disp - disp_ref).abs() / (disp_ref.abs() + 1.0)
     d5 = {"disp_err_max": float(err.max()), "disp_err_frac_below_1e-3": float((err < 1e-3).float().mean()),

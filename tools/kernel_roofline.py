@@ -113,9 +113,15 @@ def measured_traffic(symbol):
     raise LookupError("%s has no entry for %s -- re-run tools/profile_round.sh" % (os.path.basename(path), symbol))
 
 
-def step_kernel_table(sampler, reps=3):
-    """HIP-event timing of every C-ABI launch of `reps` eager steps -> {symbol: [n, ms, flops, bytes]}."""
+def step_kernel_table(sampler, reps=3, overlapped=False):
+    """HIP-event timing of every C-ABI launch of `reps` eager steps -> {symbol: [n, ms, flops, bytes]}.
+    overlapped=False: the blocks' two halves run on ONE stream for the measurement, so an event bracket times a
+    kernel that has the chip to itself (what a kernel roofline is about); True: as the step really runs (two
+    streams), where a launch shares the CUs with the other half's kernels and its bracket is longer."""
+    from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
     lib = _lib.load()
+    saved_par = FN.PAR_DEEP
+    FN.PAR_DEEP = bool(overlapped) and saved_par
     records = []
     installed = []
     for name in _TIMED:
@@ -140,6 +146,7 @@ def step_kernel_table(sampler, reps=3):
                 sampler._step()           # eager: the graph is not involved
         torch.cuda.synchronize()
     finally:
+        FN.PAR_DEEP = saved_par
         for name, fn in installed:
             setattr(lib, name, fn)        # back to the CDLL's own (typed) function object
     table = collections.OrderedDict()
@@ -172,6 +179,16 @@ def dominant_kernel_roofline(sampler, reps=3):
     sym, (n, ms, fl, by) = ranked[0]
     out = _roof(fl, by, ms, sym)
     try:
+        ovl = step_kernel_table(sampler, 2, overlapped=True).get(sym)
+        if ovl:
+            r = _roof(ovl[2], ovl[3], ovl[1], sym)
+            out["in_step_two_streams"] = {"avg_launch_us": round(ovl[1] / ovl[0] * 1e3, 2), "achieved": r["achieved"],
+                                          "frac": r["frac"],
+                                          "note": "same launches while the other half of each block runs beside them "
+                                                  "(how the step executes; agrees with profiles/*_bench_kernel_stats.csv)"}
+    except Exception as e:   # instrumentation only
+        out["in_step_two_streams"] = {"error": repr(e)}
+    try:
         out["traffic"], out["traffic_source"] = measured_traffic(sym)
     except (LookupError, OSError, KeyError, ValueError) as e:
         out["traffic"], out["traffic_error"] = None, str(e)
@@ -180,8 +197,9 @@ def dominant_kernel_roofline(sampler, reps=3):
         "kernel": sym, "launches_per_step": n // reps, "avg_launch_us": round(ms / n * 1e3, 2),
         "avg_gflop_per_launch": round(fl / n / 1e9, 3), "avg_algorithmic_MB_per_launch": round(by / n / 1e6, 2),
         "share_of_step_kernel_time": round(ms / total, 4),
-        "note": "dominant = largest HIP-event time among the C-ABI launches of %d eager steps (events on the launch "
-                "stream include ~3 us of eager launch latency per call; rocprof durations are in profiles/)" % reps,
+        "note": "dominant = largest HIP-event time among the C-ABI launches of %d eager steps with the blocks' halves "
+                "serialised on one stream (a kernel alone on the chip; agrees with profiles/*_bench_kernel_stats_serial"
+                ".csv); events include ~3 us of eager launch latency per call" % reps,
         "next": [{"kernel": s, "share": round(v[1] / total, 4), **_roof(v[2], v[3], v[1], s)} for s, v in ranked[1:6]],
     })
     return out

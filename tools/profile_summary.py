@@ -144,14 +144,21 @@ def main():
     mmap = {r["kernel"]: r for r in mfma}
     rows, total = [], sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
     nsteps = 20 + 3 + 2          # timed + warm-up + two first steps (bench.py: begin x2)
+    serial = {}
+    sp = os.path.join(out, tag + "_bench_kernel_stats_serial.csv")
+    if os.path.exists(sp):
+        serial = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sp))}
     for r in stats:
         share = float(r["TotalDurationNs"]) / total
         if share < 0.003:
             continue
         k = short(r["Name"])
-        avg_us = float(r["AverageNs"]) / 1e3
+        in_step = float(r["AverageNs"]) / 1e3
+        # rates are quoted on the duration of a launch that has the chip to itself (serial pass: the two halves of
+        # every block on one stream); in the step the halves overlap and a launch's wall time is longer
+        avg_us = serial.get(k, in_step)
         row = {"kernel": k, "share_of_gpu_time": round(share, 4), "avg_us": round(avg_us, 2),
-               "launches_per_step": round(int(r["Calls"]) / nsteps, 1)}
+               "avg_us_in_step": round(in_step, 2), "launches_per_step": round(int(r["Calls"]) / nsteps, 1)}
         t = tmap.get(k)
         if t:
             gbs = t["hbm_bytes_per_launch"] / (avg_us * 1e-6) / 1e9
