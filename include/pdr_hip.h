@@ -204,6 +204,12 @@ typedef struct {
    * whenever gcnt is given. */
   int g_zrow;
   int g_reserved;
+  /* kNN form of a gathered source (both non-NULL; group_knn's first conv, see pdr_gather_add): the value gets two
+   * more per-position terms  + gs1[p] * g_r1[c] + gs2[p] * g_r2[c]  (gs1 = squared distance, gs2 = interpolation
+   * weight of position p, in pdr_layer_in_t; g_r1 / g_r2 = the conv's rows of those two channels, offset to this
+   * segment's first column, readable up to the segment's 4-padded width).  No empty balls in this form. */
+  const float *g_r1;
+  const float *g_r2;
 } pdr_seg_t;
 
 typedef struct {
@@ -225,6 +231,8 @@ typedef struct {
   const float *oadd;
   int oadd_ld;
   int oadd_div;         /* power of two */
+  const float *gs1;     /* (P) per-position scalars of kNN-form gathered sources (see pdr_seg_t.g_r1), or NULL */
+  const float *gs2;
 } pdr_layer_in_t;
 
 /* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into
@@ -235,7 +243,8 @@ int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
 int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 /* The launch pdr_fused_layer would make for these arguments, without launching (profilers attribute a call
  * to its kernel symbol): out[0..5] = {wave-specialised kernel (csrc/fused_layer_ws.hip)?, tile variant id,
- * residual source?, gathered source?, float4 staging?, split-bf16 arithmetic?}.  Same return codes as
+ * residual source?, gathered source (0 none, 1 ball form, 2 kNN form), float4 staging?, split-bf16 arithmetic?}.
+ * Same return codes as
  * pdr_fused_layer.  Process-wide tuning knob read once: PDR_FUSED_WS=0 selects the uniform-wave kernels. */
 int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw, int Cout,
                          const float *Y, int ldy, int *out);

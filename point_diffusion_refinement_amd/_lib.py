@@ -63,14 +63,15 @@ SIGNATURES = {
 
 class Seg(_c.Structure):
     _fields_ = [("ptr", _P), ("C", _I), ("ld", _I), ("row_div", _I), ("gV", _P), ("gV0", _P), ("g_ldv", _I),
-                ("g_nsrc", _I), ("g_zrow", _I), ("g_reserved", _I)]
+                ("g_nsrc", _I), ("g_zrow", _I), ("g_reserved", _I), ("g_r1", _P), ("g_r2", _P)]
 
 
 class LayerIn(_c.Structure):
     """pdr_layer_in_t of include/pdr_hip.h."""
     _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("rseg", Seg),
                 ("add_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I), ("gidx", _P),
-                ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I)]
+                ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I),
+                ("gs1", _P), ("gs2", _P)]
 _lib = None
 
 

@@ -723,7 +723,7 @@ extern "C" int pdr_fused_layer_variant(int rows_per_batch, int Cout) {
 namespace {
 struct LayerPlan {
   TileCfg t;
-  bool vec, gath, radd, ws;
+  bool vec, gath, radd, ws, knn;
   long ntiles;
   int ncol;
 };
@@ -797,6 +797,9 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
     for (int sg = 0; sg < in->n_seg; ++sg)
       if (in->seg[sg].gV && in->gcnt && !in->seg[sg].gV0) return PDR_EINVAL;
   }
+  bool knn = false;
+  for (int sg = 0; sg < in->n_seg; ++sg) knn = knn || in->seg[sg].g_r1 || in->seg[sg].g_r2;
+  pl->knn = knn;
   pl->vec = vec;
   pl->gath = gath;
   pl->radd = radd;
@@ -806,7 +809,8 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
 }
 }  // namespace
 
-// out[0..5] = {wave-specialised kernel?, tile variant id, residual source?, gathered source?, float4 staging?,
+// out[0..5] = {wave-specialised kernel?, tile variant id, residual source?, gathered source (0 no / 1 ball / 2 kNN),
+// float4 staging?,
 // split-bf16 arithmetic?} of the launch pdr_fused_layer would make for these arguments.
 extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw, int Cout,
                                     const float* Y, int ldy, int* out) {
@@ -817,7 +821,7 @@ extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, c
   out[0] = pl.ws;
   out[1] = pl.t.id;
   out[2] = pl.radd;
-  out[3] = pl.gath;
+  out[3] = pl.gath ? (pl.knn ? 2 : 1) : 0;
   out[4] = pl.vec;
   out[5] = 0;
   return PDR_OK;
@@ -849,6 +853,8 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
       pdr::launch_fused_layer_ws(t.id, radd, gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt,
                                  ncol, s))
     return pdr::check_launch();
+  // kNN-form gathered sources exist in the wave-specialised kernel only: the caller materialises instead
+  if (pl.knn) return PDR_EUNSUPPORTED;
 #define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC, GATH)                                            \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC, GATH>), grid, dim3(256), 0, s, \
                      *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt)

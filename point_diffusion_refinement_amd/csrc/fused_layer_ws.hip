@@ -90,7 +90,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // byte offset of k-granule g (8 bf16 = 16 B) of row r inside a [rows][64 B] image
 __device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ ((r >> 2) & 3)) << 4); }
 
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool GATH = false, bool SPLIT = false>
+// GATH: 0 = plain sources, 1 = gathered ball-query first conv (U[idx] + V, empty balls), 2 = gathered kNN first conv
+// (U[idx] + V + d2 r1 + w r2: the two per-position terms of group_knn's distance / weight channels)
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool SPLIT = false>
 __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
@@ -187,8 +189,13 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // GATHERED sources (first conv of a grouped block consumed without materialising it, see
     // pdr_gather_add): x[p] = U[b, idx[p]] + V[p / K]; an empty ball reads the table's zero row + V0.
     // Per tile: this thread's neighbour indices (-1 = empty ball); per (tile, segment): byte offsets.
-    int g_idx[GATH ? APT4 : 1], n_idx[GATH ? APT4 : 1], n_cnt[GATH ? APT4 : 1];
+    // (the kNN form has no ball counts and, for the sake of its register budget -- two more per-position values and
+    // two more row quads live in the producer -- no next-tile index prefetch)
+    int g_idx[GATH ? APT4 : 1], n_idx[GATH == 1 ? APT4 : 1], n_cnt[GATH == 1 ? APT4 : 1];
     unsigned v_off[GATH ? APT4 : 1];
+    constexpr bool KNN = GATH == 2;
+    float gs1v[KNN ? APT4 : 1], gs2v[KNN ? APT4 : 1];   // per tile: d2 / weight of this thread's positions
+    f32x4 Rq1, Rq2;                                      // per chunk: the conv rows of those two channels
     int g_tile = -1, n_tile = -1;
     const int gsh = GATH ? __builtin_ctz(in.gK) : 0;
     bool Rgath = false;                                // chunk in flight comes from a gathered segment
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       if constexpr (GATH) {
         if (c.tile != g_tile) {                                  // uniform: first chunk of a tile
           off_sg = -1;
-          if (c.tile == n_tile) {
+          if (GATH == 1 && c.tile == n_tile) {
             // indices prefetched while the previous tile's last chunk was fetched: the dependent
             // index -> row load chain is off the per-tile critical path
 #pragma unroll
@@ -227,10 +234,19 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
               g_idx[i] = cnt <= 0 ? -1 : id;
             }
           }
+          if constexpr (KNN) {
+            // consumed at the commit of this tile's first chunk, one chunk period from now: no prefetch needed
+#pragma unroll
+            for (int i = 0; i < APT4; ++i) {
+              const long p = row0 + min(vr0 + VSTEP * i, nvalid - 1);
+              gs1v[i] = in.gs1[p];
+              gs2v[i] = in.gs2[p];
+            }
+          }
           g_tile = c.tile;
         }
         const int nt = c.tile + static_cast<int>(gridDim.x);
-        if (last_of_tile(c) && nt < n_row_tiles) {              // uniform: prefetch the next tile's indices
+        if (GATH == 1 && last_of_tile(c) && nt < n_row_tiles) { // uniform: prefetch the next tile's indices
           const int nb = nt / tpb, ntb = nt - nb * tpb;
           const long nrow0 = static_cast<long>(nb) * rpb + static_cast<long>(ntb) * TM;
           const int nnv = min(TM, rpb - ntb * TM);
@@ -345,6 +361,14 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           const char* vb = reinterpret_cast<const char*>(seg.gV + (row0 >> gsh) * seg.g_ldv + c.ks);
 #pragma unroll
           for (int i = 0; i < APT4; ++i) Rrv2[i] = *reinterpret_cast<const float4*>(vb + vo[i]);
+          if constexpr (KNN) {
+            // this thread's four channels of the d2 / weight rows (4-byte aligned in general; the column
+            // offset stays inside the segment's 4-padded width, as for the A loads)
+            const unsigned qo = Rkmax == KC ? 16u * vc4
+                                            : static_cast<unsigned>(min(4 * vc4, ((seg.C + 3) & ~3) - 4 - c.ks)) * 4u;
+            __builtin_memcpy(&Rq1, reinterpret_cast<const char*>(seg.g_r1 + c.ks) + qo, 16);
+            __builtin_memcpy(&Rq2, reinterpret_cast<const char*>(seg.g_r2 + c.ks) + qo, 16);
+          }
         }
       }
       if constexpr (RADD) {
@@ -371,6 +395,13 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           if constexpr (GATH) {
             if (Rgath) {   // uniform: neighbour row + query row
               x[0] += Rrv2[i].x; x[1] += Rrv2[i].y; x[2] += Rrv2[i].z; x[3] += Rrv2[i].w;
+              if constexpr (KNN) {   // + d2 r1 + w r2, in pdr_gather_add's order (same bits as its statistics saw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  x[j] = __builtin_fmaf(gs1v[i], Rq1[j], x[j]);
+                  x[j] = __builtin_fmaf(gs2v[i], Rq2[j], x[j]);
+                }
+              }
             }
           }
           float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -733,6 +764,14 @@ namespace pdr {
 bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin) {
   if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
   if (id == 3 || id > 5) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
+  bool knn = false;
+  for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
+  if (knn) {
+    // kNN-form gathered sources: both per-position arrays, both rows on every gathered segment, no empty balls
+    if (!gath || radd || !in.gs1 || !in.gs2 || in.gcnt) return false;
+    for (int sg = 0; sg < in.n_seg; ++sg)
+      if (in.seg[sg].gV && (!in.seg[sg].g_r1 || !in.seg[sg].g_r2)) return false;
+  }
   if (gath) {
     // gathered sources here: plain residual only; empty balls through the table's zero row and a V0
     // that sits a small non-negative offset behind V (one allocation)
@@ -766,17 +805,21 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
                      Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles)
+  bool knn = false;
+  for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
 #define PDR_WS(RT, CT, WR, WC, KC)                            \
   do {                                                        \
-    if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, true, false);  \
-    else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, false, false); \
-    else PDR_WS_K(RT, CT, WR, WC, KC, false, false, false);   \
+    if (gath && knn) PDR_WS_K(RT, CT, WR, WC, KC, false, 2, false); \
+    else if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, 1, false);  \
+    else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, false); \
+    else PDR_WS_K(RT, CT, WR, WC, KC, false, 0, false);       \
   } while (0)
 #define PDR_WS_SPLIT(RT, CT, WR, WC, KC)                      \
   do {                                                        \
-    if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, true, true);   \
-    else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, false, true); \
-    else PDR_WS_K(RT, CT, WR, WC, KC, false, false, true);    \
+    if (gath && knn) PDR_WS_K(RT, CT, WR, WC, KC, false, 2, true); \
+    else if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, 1, true);   \
+    else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, true); \
+    else PDR_WS_K(RT, CT, WR, WC, KC, false, 0, true);        \
   } while (0)
   if (split) {
     if (id == 4) PDR_WS_SPLIT(2, 2, 2, 2, 32);

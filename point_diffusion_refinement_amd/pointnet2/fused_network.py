@@ -59,6 +59,9 @@ AHEAD_LEVEL = int(__import__("os").environ.get("PDR_AHEAD_LEVEL", "99"))
 # what rounds of this code did before; kept for A/B and as the cross-check of the tests).
 FUSE_CONDITION_BRANCH = __import__("os").environ.get("PDR_FUSE_CONDITION_BRANCH", "1") == "1"
 USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1"
+# The same for the kNN (feature-propagation) blocks: consumers add the two per-position terms d2 r1 + w r2 in their
+# producer waves (GATH = 2 instantiations of the layer kernel).  PDR_VIRTUAL_KNN=0: materialised (A/B).
+USE_VIRTUAL_KNN = __import__("os").environ.get("PDR_VIRTUAL_KNN", "1") == "1"
 # Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
 # FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
 # Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
@@ -86,6 +89,8 @@ def _fill_seg(cseg, seg):
         cseg.gV0 = _ptr(g["V0"][0], g["V0"][1]) if g.get("V0") is not None else None
         cseg.g_ldv, cseg.g_nsrc = g["ldv"], g["nsrc"]
         cseg.g_zrow = g.get("zrow", -1)
+        if g.get("r1") is not None:                     # kNN form: + s1[p] r1[c] + s2[p] r2[c]
+            cseg.g_r1, cseg.g_r2 = _ptr(g["r1"][0], g["r1"][1]), _ptr(g["r2"][0], g["r2"][1])
 
 
 class Act:
@@ -101,6 +106,8 @@ class Act:
         self.C = sum(s[2] for s in segs)
         self.gidx = self.gcnt = None   # shared neighbour index / ball counts of gathered segments
         self.gK = 0
+        self.gs1 = self.gs2 = None     # kNN form: per-position distance / weight of gathered segments
+        self.first = None              # the FirstOut the gathered segments come from (fallback: materialise)
         self.ss_ld = 0                 # leading dimension of scale / shift (0 = C)
         self.oadd = None               # (tensor (rows, ld), div): output-side per-query add
 
@@ -123,6 +130,8 @@ class Act:
             li.gidx = self.gidx.data_ptr()
             li.gcnt = self.gcnt.data_ptr() if self.gcnt is not None else None
             li.gK = self.gK
+            if self.gs1 is not None:
+                li.gs1, li.gs2 = self.gs1.data_ptr(), self.gs2.data_ptr()
         return li
 
 
@@ -133,10 +142,12 @@ class FirstOut:
     materialised (`Yres`): they are consumed as a row-wise residual, which stays a plain read."""
 
     def __init__(self, Y=None, U=None, V2=None, ld=0, has_v0=False, idx=None, counts=None, K=0, nsrc=0, zrow=-1,
-                 Yres=None, res_col0=0, res_cols=0):
+                 Yres=None, res_col0=0, res_cols=0, s1=None, s2=None, r1=None, r2=None, materialise=None):
         self.Y, self.U, self.V2, self.ld, self.has_v0 = Y, U, V2, ld, has_v0
         self.idx, self.counts, self.K, self.nsrc, self.zrow = idx, counts, K, nsrc, zrow
         self.Yres, self.res_col0, self.res_cols = Yres, res_col0, res_cols
+        self.s1, self.s2, self.r1, self.r2 = s1, s2, r1, r2          # kNN form (r1 / r2: padded conv rows)
+        self.materialise = materialise                                # (col0, C) -> (P, pad4(C)) tensor
 
     @property
     def virtual(self):
@@ -149,11 +160,14 @@ class FirstOut:
             return (self.Yres, col0 - self.res_col0, C, self.Yres.shape[1], 1)
         g = {"V": (self.V2, col0), "V0": (self.V2, self.ld + col0) if self.has_v0 else None,
              "ldv": self.V2.shape[1], "nsrc": self.nsrc, "zrow": self.zrow}
+        if self.s1 is not None:
+            g["r1"], g["r2"] = (self.r1, col0), (self.r2, col0)
         return (self.U, col0, C, self.U.shape[1], 1, g)
 
     def attach(self, act):
         if self.virtual:
             act.gidx, act.gcnt, act.gK = self.idx, self.counts, self.K
+            act.gs1, act.gs2, act.first = self.s1, self.s2, self
         return act
 
 
@@ -327,9 +341,22 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
     li = act.struct()
     rc0 = conv.Cout if relu_col0 is None else relu_col0
     if not _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, rc0):
-        _lib.check(lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
-                                       conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
-                                       partial.data_ptr() if stats else None, rc0, _stream()), "fused_layer")
+        rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
+                                 conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
+                                 partial.data_ptr() if stats else None, rc0, _stream())
+        if rc == _lib.PDR_EUNSUPPORTED and act.gs1 is not None and act.first is not None:
+            # a kNN-form gathered source reached a tile shape without a wave-specialised kernel: materialise the
+            # columns it reads (one pdr_gather_add window per segment) and run the layer on plain sources
+            segs = [(act.first.materialise(sg[1], sg[2]), 0, sg[2], _pad4(sg[2]), 1) if len(sg) > 5 and sg[5] else sg
+                    for sg in act.segs]
+            plain_act = Act(segs, act.P, act.B, act.rpb, scale=act.scale, shift=act.shift, add=act.add,
+                            add_ld=act.add_ld, radd=act.radd, pre_relu=act.pre_relu, post_relu=act.post_relu)
+            plain_act.ss_ld, plain_act.oadd = act.ss_ld, act.oadd
+            li = plain_act.struct()
+            rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
+                                     conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
+                                     partial.data_ptr() if stats else None, rc0, _stream())
+        _lib.check(rc, "fused_layer")
     return Y, partial, tpb
 
 
@@ -620,7 +647,9 @@ class SplitFirstConv:
             self.V0 = _RawConv(W_abs + W_ctr, bias, Cout)
             self.r1 = self.r2 = None
         else:
-            self.r1, self.r2 = Wt[Cs].contiguous(), Wt[Cs + 1].contiguous()
+            # (4 floats of slack: consumers read these rows in 16-byte pieces up to a segment's 4-padded width)
+            pad = torch.zeros(4, device=dev)
+            self.r1, self.r2 = torch.cat([Wt[Cs], pad]).contiguous(), torch.cat([Wt[Cs + 1], pad]).contiguous()
             W_abs, W_rel, W_x = Wt[Cs + 2:Cs + 5], Wt[Cs + 5:Cs + 8], Wt[Cs + 8:Cs + 11]
             self.U = _RawConv(torch.cat([W_f, W_abs + W_rel], 0), zb, Cout)
             self.V = _RawConv(W_x - W_rel, bias, Cout)
@@ -669,7 +698,8 @@ class SplitFirstConv:
         ldv = V2.shape[1]
         rpb = m * K
         tpb = (rpb + 127) // 128
-        virtual = virtual and s1 is None and s2 is None and (K & (K - 1)) == 0 and 128 % K == 0
+        virtual = virtual and (s1 is None) == (s2 is None) and (K & (K - 1)) == 0 and 128 % K == 0 and \
+            not (s1 is not None and has_v0)
         Y = None if virtual else torch.empty((B * rpb, ld), dtype=torch.float32, device=U.device)
         partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
         cptr = counts.data_ptr() if has_v0 else None
@@ -693,9 +723,21 @@ class SplitFirstConv:
         else:
             res = None
             gather_add(None, ld, 0, -1)
+        def materialise(col0, C):
+            """Columns [col0, col0 + C) of the conv output as a tensor (fallback of consumers that cannot gather)."""
+            assert col0 % 4 == 0
+            Yc = torch.empty((B * rpb, _pad4(C)), dtype=torch.float32, device=U.device)
+            _lib.check(lib.pdr_gather_add(
+                U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
+                s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
+                s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
+                B, rpb, K, self.Cout, Yc.data_ptr(), Yc.shape[1], None, relu_col0, col0, C, _stream()), "gather_add")
+            return Yc
+
         first = FirstOut(U=U, V2=V2, ld=ld, has_v0=has_v0, idx=idx32, counts=counts if has_v0 else None, K=K,
                          nsrc=n, zrow=B * n, Yres=Yres, res_col0=res[0] if res else 0,
-                         res_cols=res[1] if res else 0)
+                         res_cols=res[1] if res else 0, s1=s1, s2=s2, r1=self.r1 if s1 is not None else None,
+                         r2=self.r2 if s1 is not None else None, materialise=materialise)
         return first, partial, tpb
 
 
@@ -833,8 +875,10 @@ class FusedKnnFP:
         if USE_SPLIT_FIRST:
             if self.split is None:
                 self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
-            Y1, part1, tpb1 = self.split(known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0,
-                                         s1=d2, s2=wgt, V2=V2)
+            Y1, part1, tpb1 = self.split(
+                known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0, s1=d2, s2=wgt, V2=V2,
+                virtual=USE_VIRTUAL_FIRST and USE_VIRTUAL_KNN,
+                res=(self.mlp1.res_col0, self.mlp1.Clast) if self.mlp1.res_col0 is not None else None)
             if _PAR["stream"] is not None and B * n * K <= PAR_MAX_ROWS:
                 def chain_a():
                     hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)

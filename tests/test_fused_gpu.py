@@ -120,18 +120,21 @@ def test_fused_network_small_config(cuda, split_first, monkeypatch):
 
 
 def test_optional_fusions_match(cuda, monkeypatch):
-    """The experimental paths (virtual first conv, score+pool epilogue) stay numerically equivalent."""
+    """The optional paths (virtual first conv of the ball and of the kNN blocks, score+pool epilogue) stay
+    numerically equivalent, on and off."""
     net, fused = _pair(small_fused_config(), 22, cuda)
     g = torch.Generator().manual_seed(6)
     x = torch.randn(2, 256, 3, generator=g).to(cuda)
     cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
     ts, label = torch.tensor([9.0, 4.0], device=cuda), torch.tensor([1, 7], device=cuda)
     base, _ = _cached_eps(net, fused, x, cond, ts, label)
-    for flag in ("FUSE_SCORE_POOL", "USE_VIRTUAL_FIRST"):
-        monkeypatch.setattr(FN, flag, True)
-        got, _ = _cached_eps(net, fused, x, cond, ts, label)
-        monkeypatch.setattr(FN, flag, False)
-        assert ((got - base).abs() / (base.abs() + 1.0)).max() < 1e-3, flag
+    for flag in ("FUSE_SCORE_POOL", "USE_VIRTUAL_FIRST", "USE_VIRTUAL_KNN"):
+        default = getattr(FN, flag)
+        for value in (True, False):
+            monkeypatch.setattr(FN, flag, value)
+            got, _ = _cached_eps(net, fused, x, cond, ts, label)
+            assert ((got - base).abs() / (base.abs() + 1.0)).max() < 1e-3, (flag, value)
+        monkeypatch.setattr(FN, flag, default)
 
 
 def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
@@ -240,7 +243,8 @@ def test_graphed_fast_sampler_matches_fastdpm_reference_loop(cuda, method, sched
 
 def _random_layer_case(seed, cuda):
     """One random pdr_fused_layer problem + its float64 reference (aligned segments => the wave-specialised
-    kernel; `gath` adds a gathered first-conv source with empty balls)."""
+    kernel; `gath` adds a gathered first-conv source: ball form with empty balls on even seeds, kNN form --
+    two more per-position terms s1[p] r1[c] + s2[p] r2[c] -- on odd seeds)."""
     rng = np.random.default_rng(seed)
     g = torch.Generator().manual_seed(seed)
     rpb = int(rng.choice([16, 32, 96, 128, 160, 256, 384, 1000, 2048, 1 << 16]))   # last: many tiles per workgroup
@@ -255,7 +259,7 @@ def _random_layer_case(seed, cuda):
     Cin = sum(widths)
     Cout = int(rng.choice([3, 32, 35, 64, 96, 105, 128, 140, 200, 256, 427]))
     segs, cols = [], []
-    idx = cnt = None
+    idx = cnt = knn = dense = None
     for si, C in enumerate(widths):
         ld = (C + 3) // 4 * 4 + 4 * int(rng.integers(0, 2))
         if gath and si == 0:
@@ -267,11 +271,23 @@ def _random_layer_case(seed, cuda):
             cnt = torch.randint(0, 3, (P // K,), generator=g, dtype=torch.int32)       # 1/3 empty balls
             bsel = torch.arange(P) // rpb
             rows = U[bsel * n_src + idx.long()][:, :C] + V2[torch.arange(P) // K][:, :C]
-            empty = (cnt[torch.arange(P) // K] <= 0).unsqueeze(1)
-            cols.append(torch.where(empty, V2[torch.arange(P) // K][:, ld:ld + C], rows))
-            U, V2 = U.to(cuda), V2.to(cuda)
-            segs.append((U, 0, C, ld, 1, {"V": (V2, 0), "V0": (V2, ld), "ldv": 2 * ld, "nsrc": n_src,
-                                            "zrow": B * n_src}))
+            if seed % 2:                                                              # kNN form
+                cnt = None
+                s1, s2 = torch.rand(P, generator=g), torch.rand(P, generator=g)
+                r1, r2 = torch.randn(ld + 4, generator=g), torch.randn(ld + 4, generator=g)
+                rows = rows + s1[:, None] * r1[None, :C] + s2[:, None] * r2[None, :C]
+                knn = (s1.to(cuda), s2.to(cuda), r1.to(cuda), r2.to(cuda))
+                gd = {"V": (V2.to(cuda), 0), "V0": None, "ldv": 2 * ld, "nsrc": n_src, "zrow": B * n_src,
+                      "r1": (knn[2], 0), "r2": (knn[3], 0)}
+                dense = torch.zeros(P, (C + 3) // 4 * 4)
+                dense[:, :C] = rows
+                cols.append(rows)
+            else:
+                empty = (cnt[torch.arange(P) // K] <= 0).unsqueeze(1)
+                cols.append(torch.where(empty, V2[torch.arange(P) // K][:, ld:ld + C], rows))
+                gd = {"V": (V2.to(cuda), 0), "V0": (V2.to(cuda), ld), "ldv": 2 * ld, "nsrc": n_src,
+                      "zrow": B * n_src}
+            segs.append((U.to(cuda), 0, C, ld, 1, gd))
         else:
             div = K if rng.integers(0, 3) == 0 else 1         # neighbour-broadcast segment (also next to a gathered one)
             t = torch.randn(P // div, ld, generator=g)
@@ -306,7 +322,11 @@ def _random_layer_case(seed, cuda):
                  shift=None if shift is None else shift.to(cuda), add=None if add is None else add.to(cuda),
                  add_ld=Cin, radd=radd, pre_relu=pre, post_relu=post)
     if gath:
-        act.gidx, act.gcnt, act.gK = idx.to(cuda), cnt.to(cuda), K
+        act.gidx, act.gcnt, act.gK = idx.to(cuda), None if cnt is None else cnt.to(cuda), K
+        if knn is not None:
+            act.gs1, act.gs2 = knn[0], knn[1]
+            # what SplitFirstConv hands consumers without a kNN-gathering kernel (run_layer's fallback)
+            act.first = type("First", (), {"materialise": staticmethod(lambda col0, C: dense.to(cuda))})
     if has_oadd:
         od = torch.randn(P // K, (Cout + 3) // 4 * 4, generator=g)
         ref = ref + od[:, :Cout].repeat_interleave(K, 0).double()

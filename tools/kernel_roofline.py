@@ -43,7 +43,7 @@ def _layer_symbol(plan):
     ws, vid, radd, gath, vec, split = plan
     t = ", ".join(str(v) for v in _VARIANT[vid])
     if ws:
-        return "fused_layer_ws_kernel<%s, %s, %s, %s>" % (t, _b(radd), _b(gath), _b(split))
+        return "fused_layer_ws_kernel<%s, %s, %d, %s>" % (t, _b(radd), int(gath), _b(split))
     return "fused_layer_kernel<%s, %s, %s, %s, false>" % (t, _b(radd), _b(vec), _b(gath))
 
 
@@ -68,7 +68,7 @@ def _work(name, args, lib):
         li = args[0]._obj
         P, Cin, Cout = args[1], args[2], args[6]
         vid = lib.pdr_fused_layer_variant(li.rows_per_batch, Cout)
-        gath = any(bool(li.seg[s].gV) for s in range(li.n_seg))
+        gath = max([0] + [(2 if li.seg[s].g_r1 else 1) for s in range(li.n_seg) if li.seg[s].gV])
         byt = 4.0 * P * Cout + sum(4.0 * li.seg[s].C * (P // li.seg[s].row_div) for s in range(li.n_seg))
         if li.rseg.ptr:
             byt += 4.0 * P * Cin
