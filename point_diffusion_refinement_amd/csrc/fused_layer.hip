@@ -695,7 +695,19 @@ namespace {
 // output width (one column block => the input is read exactly once): used whenever Cout <= 160.
 // Wide outputs use 128 x 128 tiles (2 x 2 waves) over a 2-D grid.
 struct TileCfg { int tm, tn, id; };
+// narrow outputs: 128-row tiles staged in 32-channel chunks (ids 7, 8) instead of 256-row tiles in 16-channel
+// chunks (ids 0, 1): a row of <= 32 channels is then fetched as ONE whole 128-byte line (the half-line fetches of
+// the 16-channel chunks were re-read from HBM).  PDR_NARROW_KC32=0: the 256-row tiles.
+inline bool narrow_kc32() {
+  static const bool on = []() {
+    const char* e = getenv("PDR_NARROW_KC32");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 inline TileCfg pick_tile(int rows_per_batch, int Cout) {
+  if (narrow_kc32() && rows_per_batch >= 128 && Cout <= 32) return {128, 32, 7};
+  if (narrow_kc32() && rows_per_batch >= 128 && Cout <= 64) return {128, 64, 8};
   if (rows_per_batch >= 256 && Cout <= 32) return {256, 32, 0};
   if (rows_per_batch >= 256 && Cout <= 64) return {256, 64, 1};
   if (rows_per_batch >= 128 && Cout <= 96) return {128, 96, 2};
@@ -877,6 +889,8 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     case 3: PDR_LAUNCH(1, 5, 4, 1, 32); break;
     case 4: PDR_LAUNCH(2, 2, 2, 2, 32); break;
     case 5: PDR_LAUNCH(1, 2, 2, 2, 32); break;
+    case 7: PDR_LAUNCH(1, 1, 4, 1, 32); break;
+    case 8: PDR_LAUNCH(1, 2, 4, 1, 32); break;
     default: PDR_LAUNCH(1, 1, 1, 4, 32); break;
   }
 #undef PDR_LAUNCH
@@ -955,6 +969,8 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
     case 3: PDR_LAUNCH_P(1, 5, 4, 1, 32); break;
     case 4: PDR_LAUNCH_P(2, 2, 2, 2, 32); break;
     case 5: PDR_LAUNCH_P(1, 2, 2, 2, 32); break;
+    case 7: PDR_LAUNCH_P(1, 1, 4, 1, 32); break;
+    case 8: PDR_LAUNCH_P(1, 2, 4, 1, 32); break;
     default: PDR_LAUNCH_P(1, 1, 1, 4, 32); break;
   }
 #undef PDR_LAUNCH_P

@@ -763,7 +763,7 @@ namespace pdr {
 // Whether tile variant `id` (pick_tile() of fused_layer.hip) has a wave-specialised instantiation for this input.
 bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin) {
   if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
-  if (id == 3 || id > 5) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
+  if (id == 3 || id == 6 || id > 8) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   if (knn) {
@@ -833,6 +833,8 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     // case 3 (128 x 160: 80 accumulators) does not fit the 128-register budget: uniform-wave kernel
     case 4: PDR_WS(2, 2, 2, 2, 32); return true;
     case 5: PDR_WS(1, 2, 2, 2, 32); return true;
+    case 7: PDR_WS(1, 1, 4, 1, 32); return true;
+    case 8: PDR_WS(1, 2, 4, 1, 32); return true;
     default: return false;
   }
 #undef PDR_WS

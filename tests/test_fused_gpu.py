@@ -334,6 +334,96 @@ def _random_layer_case(seed, cuda):
     return act, _conv(W.to(cuda), bias.to(cuda)), ref, (B, rpb, Cout)
 
 
+def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
+    """One narrow single-source layer on 128-row tiles (tile variants 7 / 8) + float64 reference.  kind: 'plain', 'radd' (residual source) or 'gath' (ball-form gathered source, 1/3 empty balls)."""
+    g = torch.Generator().manual_seed(seed)
+    P = B * rpb
+    ld = (Cin + 3) // 4 * 4 + 4 * (seed % 2)
+    bidx = torch.arange(P) // rpb
+    act_kw, gidx = {}, None
+    if kind == "gath":
+        n_src = 3 * K
+        U = torch.randn(B * n_src + 1, ld, generator=g)
+        U[-1] = 0
+        V2 = torch.randn(P // K, 2 * ld, generator=g)
+        idx = torch.randint(0, n_src, (P,), generator=g, dtype=torch.int32)
+        cnt = torch.randint(0, 3, (P // K,), generator=g, dtype=torch.int32)
+        q = torch.arange(P) // K
+        rows = U[bidx * n_src + idx.long()][:, :Cin] + V2[q][:, :Cin]
+        x = torch.where((cnt[q] <= 0).unsqueeze(1), V2[q][:, ld:ld + Cin], rows).double()
+        V2c = V2.to(cuda)
+        seg = (U.to(cuda), 0, Cin, ld, 1, {"V": (V2c, 0), "V0": (V2c, ld), "ldv": 2 * ld, "nsrc": n_src,
+                                            "zrow": B * n_src})
+        gidx = (idx.to(cuda), cnt.to(cuda))
+    else:
+        t = torch.randn(P, ld, generator=g)
+        x = t[:, :Cin].double()
+        seg = (t.to(cuda), 0, Cin, ld, 1)
+    pre, post = bool(seed & 1), bool(seed & 2)
+    has_ss, has_add, has_oadd = bool(seed & 4) or kind == "radd", bool(seed & 8), bool(seed & 16)
+    scale = torch.randn(B, Cin, generator=g) if has_ss else None
+    shift = torch.randn(B, Cin, generator=g) if has_ss else None
+    add = torch.randn(B, Cin, generator=g) if has_add else None
+    if pre:
+        x = x.relu()
+    if has_ss:
+        x = x * scale[bidx].double() + shift[bidx].double()
+    if post:
+        x = x.relu()
+    if has_add:
+        x = x + add[bidx].double()
+    radd = None
+    if kind == "radd":
+        rt = torch.randn(P, (Cin + 3) // 4 * 4, generator=g)
+        x = x + rt[:, :Cin].double()
+        radd = (rt.to(cuda), 0, Cin, rt.shape[1], 1)
+    W = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = x @ W.t().double() + bias.double()
+    act = FN.Act([seg], P, B, rpb, scale=None if scale is None else scale.to(cuda),
+                 shift=None if shift is None else shift.to(cuda), add=None if add is None else add.to(cuda),
+                 add_ld=Cin, radd=radd, pre_relu=pre, post_relu=post)
+    if gidx is not None:
+        act.gidx, act.gcnt, act.gK = gidx[0], gidx[1], K
+    if has_oadd:
+        od = torch.randn(P // K, (Cout + 3) // 4 * 4, generator=g)
+        ref = ref + od[:, :Cout].repeat_interleave(K, 0).double()
+        act.oadd = (od.to(cuda), K)
+    return act, _conv(W.to(cuda), bias.to(cuda)), ref
+
+
+@pytest.mark.parametrize("kind", ["plain", "radd", "gath"])
+def test_narrow_layers_on_128_row_tiles(cuda, kind):
+    """Tile variants 7 / 8 (128 rows, 32-channel chunks: the level-0 / level-1 narrow layers): channel counts that
+    end inside a chunk, all prologue / epilogue options, more tiles than resident workgroups (persistent loop) with
+    an odd number of tiles per cloud, one-tile clouds."""
+    lib = _lib.load()
+    shapes = [(3, 128, 32, 32), (2, 256, 17, 32), (2, 384, 41, 32), (1, 1024, 44, 64), (2, 128, 64, 64),
+              (3, 2048, 33, 64), (2, 4096, 48, 32), (5, 128 * 1365, 32, 32), (3, 128 * 1501, 64, 64)]
+    for n, (B, rpb, Cin, Cout) in enumerate(shapes):
+        for seed in ((n, n + 13, n + 31) if rpb < 100000 else (n + 7,)):
+            act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind)
+            plan = (ctypes.c_int * 8)()
+            li = act.struct()
+            Y0 = torch.empty(1, device=cuda)
+            assert lib.pdr_fused_layer_plan(ctypes.byref(li), act.P, Cin, conv.Wt.data_ptr(), conv.ldw, Cout,
+                                            Y0.data_ptr(), (Cout + 3) // 4 * 4, plan) == 0
+            assert plan[0] == 1 and plan[1] == (7 if Cout <= 32 else 8), (kind, B, rpb, Cin, Cout, list(plan[:6]))
+            rc0 = (0, Cout // 2 + 1, Cout)[seed % 3]
+            Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=rc0)
+            torch.cuda.synchronize()
+            assert tpb == rpb // 128
+            got = Y[:, :Cout].double().cpu()
+            assert torch.isfinite(got).all()
+            assert _rel(got, ref) < 5e-5, (kind, B, rpb, Cin, Cout, seed, _rel(got, ref))
+            f = ref.clone()
+            f[:, rc0:] = f[:, rc0:].relu()
+            s1 = f.view(B, rpb, Cout).sum(1)
+            s2 = (f * f).view(B, rpb, Cout).sum(1)
+            st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
+            assert _rel(st[..., 0], s1) < 2e-4 and _rel(st[..., 1], s2) < 2e-4, (kind, B, rpb, Cin, Cout, seed)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("ws", ["1", "0"])
 def test_fused_layer_random_sweep(cuda, ws, monkeypatch):

@@ -17,6 +17,7 @@ SHAPES = [  # (rows per batch element, Cin, Cout) at B = 32
     (512, 512, 512), (512, 651, 256), (65536, 32, 32), (32768, 64, 64), (65536, 41, 32), (8192, 64, 128),
     (4096, 512, 512), (16384, 512, 512), (16384, 256, 256),   # steady-state probes (not network shapes)
     (512, 128, 128), (512, 64, 64), (2048, 64, 64), (2048, 128, 128), (512, 256, 256), (128, 512, 512),  # deep levels
+    (64, 256, 256), (256, 256, 256), (256, 128, 128), (64, 192, 192), (512, 512, 512), (16, 512, 512),   # 21..26
 ]
 
 

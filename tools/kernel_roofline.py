@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # tile variants of pdr_fused_layer (csrc/fused_layer.hip pick_tile / launch tables): id -> <RT, CT, WR, WC, KC>
 _VARIANT = {0: (2, 1, 4, 1, 16), 1: (2, 2, 4, 1, 16), 2: (1, 3, 4, 1, 32), 3: (1, 5, 4, 1, 32), 4: (2, 2, 2, 2, 32),
-            5: (1, 2, 2, 2, 32), 6: (1, 1, 1, 4, 32)}
+            5: (1, 2, 2, 2, 32), 6: (1, 1, 1, 4, 32), 7: (1, 1, 4, 1, 32), 8: (1, 2, 4, 1, 32)}
 
 
 def _b(x):
