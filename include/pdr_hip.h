@@ -23,10 +23,13 @@
  *   - return value: PDR_OK (0) or a negative PDR_E* code.  Nothing prints or
  *     calls exit() (contrast cuda_utils.h:30-39).  No hidden allocation, no
  *     device synchronisation, no mutable global state: calls are thread-safe and
- *     capturable into a hipGraph.  The only process-wide inputs are two tuning
- *     knobs read ONCE from the environment (kernel selection only, results are
- *     identical): PDR_FUSED_WS=0 (uniform-wave layer kernels) and PDR_FPS_WAVE=0|2
- *     (furthest-point-sampling kernel family, see pdr_furthest_point_sampling).
+ *     capturable into a hipGraph.  The only process-wide inputs are three tuning
+ *     knobs read ONCE from the environment (kernel selection only; results are
+ *     identical, for the layer kernels up to fp32 summation order):
+ *     PDR_FUSED_WS=0 (uniform-wave layer kernels), PDR_NARROW_KC32=0 (256-row
+ *     tiles for outputs of <= 64 channels, see pdr_fused_layer_tile_rows) and
+ *     PDR_FPS_WAVE=0|2 (furthest-point-sampling kernel family, see
+ *     pdr_furthest_point_sampling).
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined
  *     behaviour, as in the reference's kernels).
@@ -235,11 +238,13 @@ typedef struct {
   const float *gs2;
 } pdr_layer_in_t;
 
-/* rows per workgroup tile chosen for `rows_per_batch` (128/64/32); a batch element is cut into
- * ceil(rows_per_batch / tile) tiles, the last one possibly partial */
+/* rows per workgroup tile chosen for `rows_per_batch` and `Cout` (256/128/64/32); a batch element is cut
+ * into ceil(rows_per_batch / tile) tiles, the last one possibly partial.  This is the row count behind each
+ * row of the `partial` statistics of pdr_fused_layer. */
 int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
-/* index of the kernel instantiation used for this shape: 0 256x32, 1 256x64, 2 128x96, 3 128x160,
- * 4 128x128 (2-D grid), 5 64x128, 6 32x128 */
+/* index of the kernel instantiation used for this shape: 0 256x32, 1 256x64 (16-channel chunks; with
+ * PDR_NARROW_KC32=0 only), 2 128x96, 3 128x160, 4 128x128 (2-D grid), 5 64x128, 6 32x128, 7 128x32, 8 128x64
+ * (32-channel chunks: the default for outputs of <= 64 channels) */
 int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 /* The launch pdr_fused_layer would make for these arguments, without launching (profilers attribute a call
  * to its kernel symbol): out[0..5] = {wave-specialised kernel (csrc/fused_layer_ws.hip)?, tile variant id,
