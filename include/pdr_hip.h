@@ -247,10 +247,10 @@ int pdr_fused_layer_tile_rows(int rows_per_batch, int Cout);
  * (32-channel chunks: the default for outputs of <= 64 channels) */
 int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 /* The launch pdr_fused_layer would make for these arguments, without launching (profilers attribute a call
- * to its kernel symbol): out[0..5] = {wave-specialised kernel (csrc/fused_layer_ws.hip)?, tile variant id,
- * residual source?, gathered source (0 none, 1 ball form, 2 kNN form), float4 staging?, split-bf16 arithmetic?}.
- * Same return codes as
- * pdr_fused_layer.  Process-wide tuning knob read once: PDR_FUSED_WS=0 selects the uniform-wave kernels. */
+ * to its kernel symbol): out[0..6] (8 ints of space) = {wave-specialised kernel (csrc/fused_layer_ws.hip)?,
+ * tile variant id, residual source?, gathered source (0 none, 1 ball form, 2 kNN form), float4 staging?,
+ * split-bf16 arithmetic?, thin kernel (<= 4 input channels, no prologue; used when `partial` is NULL)?}.
+ * Same return codes as pdr_fused_layer.  Process-wide tuning knob read once: PDR_FUSED_WS=0 selects the uniform-wave kernels. */
 int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw, int Cout,
                          const float *Y, int ldy, int *out);
 /* Y (P,Cout; ld ldy) = prologue(X) . Wt + bias, Wt (Cin,Cout) row-major (the conv weight

@@ -691,6 +691,56 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 // waves stacked along the rows; wide outputs 128 x 128 tiles (2 x 2 waves); small batch
 // elements (few rows per GroupNorm instance) shrink the row tile.
 namespace {
+// Layers with <= 4 input channels and no prologue -- the per-query / per-source coordinate tables of the split
+// first convs, xyz . W (+ bias): three fmas per output and a pure write stream, not a job for 32 x 32 MFMA tiles
+// (30 launches per step).  A thread owns 4 consecutive output columns of one row; accumulation order = the tile
+// kernels' (bias first, then the channels in MFMA order), so the results are the same bits.
+__global__ __launch_bounds__(256) void fused_layer_thin_kernel(const float* __restrict__ X, int ldx, int shift,
+                                                               int Cin, const float* __restrict__ Wt, int ldw,
+                                                               const float* __restrict__ bias, int Cout,
+                                                               float* __restrict__ Y, int ldy, long P, int qshift) {
+  // 256 threads = (256 >> qshift) rows x (1 << qshift) column quads; a thread keeps its quad's weights in registers
+  // and walks kThinIters rows; a wave stores whole contiguous row pieces
+  constexpr int kThinIters = 8;
+  const int ql = 1 << qshift;
+  const int cq = threadIdx.x & (ql - 1), rl = threadIdx.x >> qshift;
+  const int c0 = 4 * (static_cast<int>(blockIdx.y) * ql + cq);
+  if (c0 >= Cout) return;                             // (columns up to the 4-padded width are written)
+  const int rpp = 256 >> qshift;
+  float4 w[4];
+  float b4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    w[k] = k < Cin ? *reinterpret_cast<const float4*>(Wt + static_cast<long>(k) * ldw + c0) : make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b4[j] = (bias && c0 + j < Cout) ? bias[c0 + j] : 0.0f;
+  const long r0 = static_cast<long>(blockIdx.x) * (rpp * kThinIters) + rl;
+#pragma unroll
+  for (int it = 0; it < kThinIters; ++it) {
+    const long row = r0 + static_cast<long>(it) * rpp;
+    if (row < P) {
+      const float4 x = *reinterpret_cast<const float4*>(X + (row >> shift) * ldx);
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+      // channel order 0, 2, 1, 3: the tile kernels' first MFMA of a channel quad multiplies the pair (0, 2), the
+      // second (1, 3)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int k = ((o & 1) << 1) | (o >> 1);
+        if (k < Cin) {
+          acc[0] = __builtin_fmaf(xs[k], w[k].x, acc[0]);
+          acc[1] = __builtin_fmaf(xs[k], w[k].y, acc[1]);
+          acc[2] = __builtin_fmaf(xs[k], w[k].z, acc[2]);
+          acc[3] = __builtin_fmaf(xs[k], w[k].w, acc[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(Y + row * ldy + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+}
+}  // namespace
+
+namespace {
 // Tile shapes.  "Tall" shapes stack all four waves along the rows and give every wave the full
 // output width (one column block => the input is read exactly once): used whenever Cout <= 160.
 // Wide outputs use 128 x 128 tiles (2 x 2 waves) over a 2-D grid.
@@ -735,7 +785,7 @@ extern "C" int pdr_fused_layer_variant(int rows_per_batch, int Cout) {
 namespace {
 struct LayerPlan {
   TileCfg t;
-  bool vec, gath, radd, ws, knn;
+  bool vec, gath, radd, ws, knn, thin;
   long ntiles;
   int ncol;
 };
@@ -817,13 +867,19 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   pl->radd = radd;
   // steady-state layers (float4-staged sources): wave-specialised kernel where an instantiation exists
   pl->ws = use_ws_kernels() && vec && pdr::fused_layer_ws_supported(t.id, radd, gath, *in, Cin);
+  // <= 4 input channels, nothing to apply on the way in, 16-byte rows on both sides: the thin kernel (statistics
+  // are decided by the caller: pdr_fused_layer uses it only without `partial`)
+  pl->thin = vec && Cin <= 4 && in->n_seg == 1 && !gath && !radd && !in->scale && !in->shift && !in->add &&
+             !in->pre_relu && !in->post_relu && !in->oadd && Y && ldy % 4 == 0 &&
+             reinterpret_cast<uintptr_t>(Y) % 16 == 0 && ldw >= ((Cout + 3) & ~3) && ldy >= ((Cout + 3) & ~3) &&
+             P < (1L << 31);
   return PDR_OK;
 }
 }  // namespace
 
-// out[0..5] = {wave-specialised kernel?, tile variant id, residual source?, gathered source (0 no / 1 ball / 2 kNN),
-// float4 staging?,
-// split-bf16 arithmetic?} of the launch pdr_fused_layer would make for these arguments.
+// out[0..6] = {wave-specialised kernel?, tile variant id, residual source?, gathered source (0 no / 1 ball / 2 kNN),
+// float4 staging?, split-bf16 arithmetic?, thin kernel when called without `partial`?} of the launch
+// pdr_fused_layer would make for these arguments.
 extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw, int Cout,
                                     const float* Y, int ldy, int* out) {
   if (!out) return PDR_EINVAL;
@@ -836,6 +892,7 @@ extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, c
   out[3] = pl.gath ? (pl.knn ? 2 : 1) : 0;
   out[4] = pl.vec;
   out[5] = 0;
+  out[6] = pl.thin;
   return PDR_OK;
 }
 
@@ -861,6 +918,17 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
   const int nt = static_cast<int>(ntiles);
+  if (pl.thin && !partial) {
+    const int c4n = (Cout + 3) / 4;
+    int qshift = 3;                                    // 8 .. 64 column quads per row of threads
+    while (qshift < 6 && (1 << qshift) < c4n) ++qshift;
+    const int ql = 1 << qshift, rows_per_block = (256 >> qshift) * 8;
+    const dim3 tgrid(static_cast<unsigned>((P + rows_per_block - 1) / rows_per_block),
+                     static_cast<unsigned>((c4n + ql - 1) / ql));
+    hipLaunchKernelGGL(fused_layer_thin_kernel, tgrid, dim3(256), 0, s, in->seg[0].ptr, in->seg[0].ld,
+                       __builtin_ctz(in->seg[0].row_div), Cin, Wt, ldw, bias, Cout, Y, ldy, P, qshift);
+    return pdr::check_launch();
+  }
   if (pl.ws &&
       pdr::launch_fused_layer_ws(t.id, radd, gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt,
                                  ncol, s))

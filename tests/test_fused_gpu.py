@@ -334,6 +334,37 @@ def _random_layer_case(seed, cuda):
     return act, _conv(W.to(cuda), bias.to(cuda)), ref, (B, rpb, Cout)
 
 
+@pytest.mark.parametrize("P,rpb,Cin,Cout,div", [(2048, 64, 3, 201, 1), (65536, 2048, 3, 427, 1), (512, 16, 3, 1097, 1),
+                                               (8192, 256, 4, 32, 1), (4096, 1024, 3, 3, 1), (4096, 128, 3, 105, 8)])
+def test_thin_layer_kernel(cuda, P, rpb, Cin, Cout, div):
+    """<= 4 input channels, no prologue, no statistics (the coordinate tables of the split first convs): the thin
+    kernel must give the SAME BITS as the wave-specialised MFMA tile kernel (selected by asking for statistics) and
+    match float64."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(P + Cout)
+    x = torch.randn(P // div, 4, generator=g)
+    W = torch.randn(Cout, Cin, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    conv = _conv(W.to(cuda), bias.to(cuda))
+    B = P // rpb
+    act = FN.Act([(x.to(cuda), 0, Cin, 4, div)], P, B, rpb)
+    plan = (ctypes.c_int * 8)()
+    li = act.struct()
+    Y0 = torch.empty(4, device=cuda)
+    assert lib.pdr_fused_layer_plan(ctypes.byref(li), P, Cin, conv.Wt.data_ptr(), conv.ldw, Cout, Y0.data_ptr(),
+                                    FN._ldy(Cout), plan) == 0
+    assert plan[6] == 1
+    thin, _, _ = FN.run_layer(act, conv, stats=False)
+    tile, part, _ = FN.run_layer(act, conv, stats=True)
+    torch.cuda.synchronize()
+    if plan[0]:            # wave-specialised tile kernel: bias first, channels in MFMA order -- the same fma chain
+        assert torch.equal(thin[:, :Cout], tile[:, :Cout])
+    else:                  # uniform-wave kernel (32-row tiles): bias added last
+        assert _rel(thin[:, :Cout].double().cpu(), tile[:, :Cout].double().cpu()) < 1e-6
+    ref = x[:, :Cin].double().repeat_interleave(div, 0) @ W.t().double() + bias.double()
+    assert _rel(thin[:, :Cout].double().cpu(), ref) < 1e-5
+
+
 def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
     """One narrow single-source layer on 128-row tiles (tile variants 7 / 8) + float64 reference.  kind: 'plain', 'radd' (residual source) or 'gath' (ball-form gathered source, 1/3 empty balls)."""
     g = torch.Generator().manual_seed(seed)

@@ -63,6 +63,8 @@ def _work(name, args, lib):
                 byt += 4.0 * sg.C * (P // sg.row_div)
         if li.rseg.ptr:
             byt += 4.0 * P * Cin
+        if plan[6] and not args[9]:                      # <= 4 input channels, no prologue, no statistics
+            return "fused_layer_thin_kernel", 2.0 * P * Cin * Cout, byt
         return _layer_symbol(tuple(plan[:6])), 2.0 * P * Cin * Cout, byt
     if name == "pdr_fused_layer_bf16x3":
         li = args[0]._obj

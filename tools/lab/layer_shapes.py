@@ -41,7 +41,8 @@ def main():
         e0.record()
         rc = fn(*args)
         e1.record()
-        rows.append((P, li.rows_per_batch, Cin, Cout, "+".join(segs), flags, args[10], KR._layer_symbol(tuple(plan[:6])),
+        sym = "thin_kernel" if plan[6] and not args[9] else KR._layer_symbol(tuple(plan[:6]))
+        rows.append((P, li.rows_per_batch, Cin, Cout, "+".join(segs), flags, args[10], sym,
                      e0, e1))
         return rc
 
