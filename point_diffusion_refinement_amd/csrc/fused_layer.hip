@@ -77,17 +77,7 @@ __device__ __forceinline__ float load_col(const ColSrc& s, long row) {
 // load is `scalar base + 32-bit lane offset`.
 // Pipeline per chunk: global -> registers (prologue applied) is issued BEFORE the MFMAs of the
 // previous chunk, registers -> LDS after them: the loads overlap the matrix pipe.
-// POOL epilogue: the GEMM output is the attention SCORE of every (query, neighbour) position; instead
-// of being stored it is masked by the ball count, soft-maxed over the K neighbours of its query and
-// used to weight the value rows (attention.py:83-96) -- the (P x D) score tensor never exists.
-struct PoolArgs {
-  const float* values;   // (P, ldv) value conv output (pre-GroupNorm)
-  const float* vscale;   // (B, D) folded GroupNorm of the values, or NULL
-  const float* vshift;
-  const int* counts;     // (P / K) valid neighbours per query, or NULL = all
-  float* out;            // (P / K, ldo)
-  int ldv, ldo, K, v_relu;
-};
+using pdr::PoolArgs;   // POOL epilogue (pdr_common.h)
 
 template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC, bool GATH, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
@@ -1026,6 +1016,11 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
   const int nt = static_cast<int>(ntiles);
   PoolArgs pa{values, vscale, vshift, counts, out, ldv, ldo, K, v_relu};
+  // wave-specialised kernels carry the pooled epilogue for the tile shapes whose rows tile whole queries
+  if (use_ws_kernels() && in->rows_per_batch % t.tm == 0 &&
+      pdr::launch_fused_layer_ws(t.id, false, false, *in, Cin, Wt, ldw, bias, D, nullptr, 0, nullptr, D, nt, ncol, s,
+                                 false, &pa))
+    return pdr::check_launch();
 #define PDR_LAUNCH_P(RT, CT, WR, WC, KC)                                                              \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false, true, false, true>), grid, dim3(256), \
                      0, s, *in, Cin, Wt, ldw, bias, D, static_cast<float*>(nullptr), 0,                   \

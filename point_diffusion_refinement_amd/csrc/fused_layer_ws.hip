@@ -92,11 +92,12 @@ __device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ (
 
 // GATH: 0 = plain sources, 1 = gathered ball-query first conv (U[idx] + V, empty balls), 2 = gathered kNN first conv
 // (U[idx] + V + d2 r1 + w r2: the two per-position terms of group_knn's distance / weight channels)
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool SPLIT = false>
+// POOL: attention pooling epilogue (pdr::PoolArgs) -- the scores stay in the accumulators
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool SPLIT = false, bool POOL = false>
 __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int n_row_tiles) {
+    float* __restrict__ partial, int relu_col0, int n_row_tiles, pdr::PoolArgs pool) {
   // SPLIT: `Wt` points at the packed bf16 hi / lo weight image (pdr_pack_weights_bf16x3: per column block and
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
@@ -577,6 +578,84 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       long ldy_e = ldy;                       // same for the uniform row offsets (scalar registers)
       asm volatile("" : "+s"(ldy_e));
       const int osh = in.oadd ? __builtin_ctz(in.oadd_div) : 0;
+      if constexpr (POOL) {
+        // ---- attention pooling (whole row tiles only: the launcher guarantees rows_per_batch % TM == 0): a
+        // 32-row MFMA block holds 32 / K whole queries (K in {8, 16, 32}); for a fixed column a query's K rows sit
+        // in the 8-row register groups {r >> 2} of both lane halves.  Value rows are read in accumulator layout
+        // (a wave instruction = two 128-byte row pieces) through a running scalar row pointer + one lane offset.
+        const int K = pool.K, ksh = __builtin_ctz(K);
+        const float lo = pool.v_relu ? 0.0f : -__builtin_inff();
+        const long vrow_bytes = static_cast<long>(pool.ldv) * 4;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const long rb = row0 + (wr * RT + i) * 32;             // first row of this 32-row block (uniform)
+          int cn[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            int c = K;
+            if (pool.counts) {
+              c = pool.counts[(rb + 8 * g4) >> ksh];
+              c = c < 1 ? 1 : c;                                  // attention.py:85 clamp(min=1)
+            }
+            cn[g4] = c;
+          }
+#pragma unroll
+          for (int j = 0; j < CT; ++j) {
+            const int col = n0 + (wc * CT + j) * 32 + il_e;
+            const bool colok = col < Cout;
+            const int cc = colok ? col : 0;
+            float v[16];
+            {
+              unsigned voff = static_cast<unsigned>(4 * hi_e * pool.ldv + cc) * 4u;
+              asm volatile("" : "+v"(voff));
+              const char* q = reinterpret_cast<const char*>(pool.values + rb * pool.ldv);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                if (r > 0) q += ((r & 3) == 0 ? 5 : 1) * vrow_bytes;
+                v[r] = *reinterpret_cast<const float*>(q + voff);
+              }
+            }
+            const float vs = pool.vscale ? pool.vscale[static_cast<long>(b) * Cout + cc] : 1.0f;
+            const float vh = pool.vshift ? pool.vshift[static_cast<long>(b) * Cout + cc] : 0.0f;
+            // (in place: the scaled scores overwrite the accumulators, the activated values their raw loads)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kk = ((r & 3) + 8 * (r >> 2) + 4 * hi_e) & (K - 1);
+              // masked slots are exactly -1e9 as in the reference; base-2 exponentials (as pdr_attention_pool)
+              acc[i][j][r] = (kk < cn[r >> 2] ? acc[i][j][r] : -1e9f) * 1.44269504088896340736f;
+              v[r] = vmax(__builtin_fmaf(v[r], vs, vh), lo);
+            }
+            auto reduce = [&](auto gsz_c) __attribute__((always_inline)) {
+              constexpr int GSZ = decltype(gsz_c)::value;        // 8-row register groups per query
+#pragma unroll
+              for (int g = 0; g < 4; g += GSZ) {
+                float m = -__builtin_inff();
+#pragma unroll
+                for (int r = 4 * g; r < 4 * (g + GSZ); ++r) m = fmaxf(m, acc[i][j][r]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.0f, a = 0.0f;
+#pragma unroll
+                for (int r = 4 * g; r < 4 * (g + GSZ); ++r) {
+                  const float w = __builtin_amdgcn_exp2f(acc[i][j][r] - m);
+                  l += w;
+                  a = __builtin_fmaf(v[r], w, a);
+                }
+                l += __shfl_xor(l, 32, 64);
+                a += __shfl_xor(a, 32, 64);
+                if (hi_e == 0 && colok) pool.out[((rb + 8 * g) >> ksh) * pool.ldo + col] = a / l;
+              }
+            };
+            if (K == 8) reduce(std::integral_constant<int, 1>());
+            else if (K == 16) reduce(std::integral_constant<int, 2>());
+            else reduce(std::integral_constant<int, 4>());
+            float bj = bias_r[j];
+            asm volatile("" : "+v"(bj));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bj;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
         const int cl = (wc * CT + j) * 32 + il_e;
@@ -718,6 +797,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = bj;
       }
+      }   // !POOL
       PDR_T(2, 8 * (g / nch) + 6);
       if (has_partial) {
         // Cross-wave fold of the statistics WITHOUT a workgroup barrier (the producers would have to
@@ -794,9 +874,11 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
 // block); instantiated for the 128-column tile variants 4 and 5 only.
 bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
                            int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
-                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split) {
+                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split, const PoolArgs* pool) {
   if (!fused_layer_ws_supported(id, radd, gath, in, Cin)) return false;
   if (split && id != 4 && id != 5) return false;
+  if (pool && (radd || gath || split || in.oadd)) return false;   // pooled epilogue: plain sources, exact arithmetic
+  const PoolArgs pa = pool ? *pool : PoolArgs();
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   const long cap = (512 + ncol - 1) / ncol;
@@ -804,7 +886,10 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles)
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
+#define PDR_WS_POOL(RT, CT, WR, WC, KC)                                                                       \
+  hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, true>), grid, dim3(512), 0, s, \
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
 #define PDR_WS(RT, CT, WR, WC, KC)                            \
@@ -821,6 +906,18 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, true); \
     else PDR_WS_K(RT, CT, WR, WC, KC, false, 0, true);        \
   } while (0)
+  if (pool) {
+    switch (id) {
+      case 0: PDR_WS_POOL(2, 1, 4, 1, 16); return true;
+      case 1: PDR_WS_POOL(2, 2, 4, 1, 16); return true;
+      case 2: PDR_WS_POOL(1, 3, 4, 1, 32); return true;
+      case 4: PDR_WS_POOL(2, 2, 2, 2, 32); return true;
+      case 5: PDR_WS_POOL(1, 2, 2, 2, 32); return true;
+      case 7: PDR_WS_POOL(1, 1, 4, 1, 32); return true;
+      case 8: PDR_WS_POOL(1, 2, 4, 1, 32); return true;
+      default: return false;
+    }
+  }
   if (split) {
     if (id == 4) PDR_WS_SPLIT(2, 2, 2, 2, 32);
     else PDR_WS_SPLIT(1, 2, 2, 2, 32);
@@ -840,6 +937,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
 #undef PDR_WS
 #undef PDR_WS_SPLIT
 #undef PDR_WS_K
+#undef PDR_WS_POOL
 }
 
 }  // namespace pdr

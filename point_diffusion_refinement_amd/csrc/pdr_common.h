@@ -29,12 +29,24 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// POOL epilogue of the layer kernels: the GEMM output is the attention SCORE of every (query, neighbour) position;
+// instead of being stored it is masked by the ball count, soft-maxed over the K neighbours of its query and used to
+// weight the value rows (attention.py:83-96) -- the (P x D) score tensor never exists.
+struct PoolArgs {
+  const float* values;   // (P, ldv) value conv output (pre-GroupNorm)
+  const float* vscale;   // (B, D) folded GroupNorm of the values, or NULL
+  const float* vshift;
+  const int* counts;     // (P / K) valid neighbours per query, or NULL = all
+  float* out;            // (P / K, ldo)
+  int ldv, ldo, K, v_relu;
+};
+
 // fused_layer_ws.hip: wave-specialised layer kernel; false = no instantiation for this tile variant
 bool fused_layer_ws_supported(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin);
 bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,
                            const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
                            float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s,
-                           bool split = false);
+                           bool split = false, const PoolArgs* pool = nullptr);
 
 // ---- DPP wave reductions (wave64, gfx9 row_shr / row_bcast) -------------------
 // After wave_max_*: lane 63 holds the maximum; callers broadcast with readlane.

@@ -40,10 +40,11 @@ from .models.pointnet2_ssg_sem import calc_t_emb
 USE_SPLIT_FIRST = True
 # Attention score conv over [q.expand(K) | k]: evaluate the query half once per query (see FusedAttention)
 SPLIT_QUERY_CONV = True
-# Last attention score conv + mask + softmax + weighted sum in one kernel (scores never written).
-# Measured: 14.0 ms/step fused vs 13.5 ms/step separate -- the MFMA accumulator layout forces 4-byte
-# value loads in the epilogue, which costs more than the score round trip saves.  OFF; kept and tested.
-FUSE_SCORE_POOL = __import__("os").environ.get("PDR_FUSE_SCORE_POOL", "0") == "1"
+# Last attention score conv + mask + softmax + weighted sum in one kernel (scores never written): the pooled
+# epilogue of the wave-specialised layer kernel reduces the accumulators in place and reads the value rows in
+# accumulator layout.  Measured on MI355X (B = 32, same box, graph replay): 9.64 / 9.74 ms per step fused vs 10.30 /
+# 10.28 separate (round 1, on the uniform-wave kernel, it had lost 14.0 vs 13.5).  PDR_FUSE_SCORE_POOL=0: separate.
+FUSE_SCORE_POOL = __import__("os").environ.get("PDR_FUSE_SCORE_POOL", "1") == "1"
 # The first conv's (P x Cout) output is not written (ball-query blocks): its consumers (second MLP conv,
 # attention key) gather U[idx] + V in the producer waves of the wave-specialised layer kernel; only the
 # residual columns (a row-wise add in their consumer) are materialised, in the same pass that computes the
