@@ -201,12 +201,16 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     const int gsh = GATH ? __builtin_ctz(in.gK) : 0;
     bool Rgath = false;                                // chunk in flight comes from a gathered segment
     // one chunk in registers (plain arrays: as members of a struct one W quad ended up in scratch)
-    float4 Rrv[APT4], Rrrv[RADD ? APT4 : 1], Rrv2[GATH ? APT4 : 1];
+    // RG: the RESIDUAL is a gathered first-conv window (U_res[idx] + V_res: the residual conv of a block whose
+    // first conv is virtual) -- the main sources are plain then
+    constexpr bool RG = RADD && GATH == 1;
+    float4 Rrv[APT4], Rrv2[GATH ? APT4 : 1];
+    f32x4 Rrrv[RADD ? APT4 : 1], Rrrv2[RG ? APT4 : 1];   // (vector values: conditional float4 struct copies go through scratch)
     f32x4 Rrw[WPT4];
     float Rps[4], Rph[4], Rpa[4];
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
     // fetch: chunk at cursor c -> registers (address arithmetic + loads only)
-    auto fetch = [&](const Cur& c) {
+    auto fetch = [&](const Cur& c) __attribute__((always_inline)) {
       const int b = c.tile / tpb, tb = c.tile - b * tpb;
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
@@ -372,10 +376,29 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           }
         }
       }
-      if constexpr (RADD) {
+      if constexpr (RG) {
+        // (this instantiation is launched only for a gathered residual: no runtime branch -- conditional assignments
+        // of the chunk registers would pin them in scratch)
+        const int rs_ld = in.rseg.ld, rs_ldv = in.rseg.g_ldv, rs_nsrc = in.rseg.g_nsrc;
+        const char* rb = reinterpret_cast<const char*>(in.rseg.ptr + static_cast<long>(b) * rs_nsrc * rs_ld +
+                                                       c.cbase + c.ks);
+        const char* rvb = reinterpret_cast<const char*>(in.rseg.gV + (row0 >> gsh) * rs_ldv + c.cbase + c.ks);
+        const int rz = in.rseg.g_zrow - b * rs_nsrc;            // the zero row, relative to this cloud
+        const int rv0d = in.rseg.gV0 ? static_cast<int>(in.rseg.gV0 - in.rseg.gV) : 0;
+        const bool fast = Rkmax == KC && nvalid == TM;
+        const int colq = fast ? 4 * vc4 : min(4 * vc4, ((Cin + 3) & ~3) - 4 - c.cbase - c.ks);
+#pragma unroll
+        for (int i = 0; i < APT4; ++i) {
+          const int r = min(vr0 + VSTEP * i, nvalid - 1);
+          const int urow = g_idx[i] < 0 ? rz : g_idx[i];
+          Rrrv[i] = *reinterpret_cast<const f32x4*>(rb + static_cast<unsigned>(urow * rs_ld + colq) * 4u);
+          Rrrv2[i] = *reinterpret_cast<const f32x4*>(
+              rvb + static_cast<unsigned>((r >> gsh) * rs_ldv + colq + (g_idx[i] < 0 ? rv0d : 0)) * 4u);
+        }
+      } else if constexpr (RADD) {
         const char* rb = reinterpret_cast<const char*>(in.rseg.ptr + row0 * in.rseg.ld + c.cbase + c.ks);
 #pragma unroll
-        for (int i = 0; i < APT4; ++i) Rrrv[i] = *reinterpret_cast<const float4*>(rb + ro[i]);
+        for (int i = 0; i < APT4; ++i) Rrrv[i] = *reinterpret_cast<const f32x4*>(rb + ro[i]);
       }
 #pragma unroll
       for (int i = 0; i < WPT4; ++i) Rrw[i] = *reinterpret_cast<const f32x4*>(wb + wo[i]);
@@ -387,8 +410,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     //  - channel masks only in a segment's last, partial chunk (uniform branch);
     //  - W is stored unmasked: rows k >= kmax meet zeroed A columns (and hold finite, clamped-row
     //    data), columns >= Cout are never stored or counted.
-    auto commit = [&](int st) {
-      auto stage_a = [&](auto masked, auto pre, auto add) {
+    auto commit = [&](int st) __attribute__((always_inline)) {
+      auto stage_a = [&](auto masked, auto pre, auto add) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked)::value, PRE = decltype(pre)::value, ADD = decltype(add)::value;
 #pragma unroll
         for (int i = 0; i < APT4; ++i) {
@@ -407,7 +430,10 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           }
           float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           if constexpr (RADD) {
-            q[0] = Rrrv[i].x; q[1] = Rrrv[i].y; q[2] = Rrrv[i].z; q[3] = Rrrv[i].w;
+            q[0] = Rrrv[i][0]; q[1] = Rrrv[i][1]; q[2] = Rrrv[i][2]; q[3] = Rrrv[i][3];
+            if constexpr (RG) {   // neighbour row + query row, as pdr_gather_add would have written them
+              q[0] += Rrrv2[i][0]; q[1] += Rrrv2[i][1]; q[2] += Rrrv2[i][2]; q[3] += Rrrv2[i][3];
+            }
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -853,11 +879,15 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
       if (in.seg[sg].gV && (!in.seg[sg].g_r1 || !in.seg[sg].g_r2)) return false;
   }
   if (gath) {
-    // gathered sources here: plain residual only; empty balls through the table's zero row and a V0
-    // that sits a small non-negative offset behind V (one allocation)
-    if (radd || in.rseg.gV) return false;
-    for (int sg = 0; sg < in.n_seg; ++sg) {
-      const pdr_seg_t& g = in.seg[sg];
+    // gathered sources here: either the main sources (plain residual or none) or the residual alone (ball form);
+    // empty balls through the table's zero row and a V0 that sits a small non-negative offset behind V (one
+    // allocation)
+    bool main_g = false;
+    for (int sg = 0; sg < in.n_seg; ++sg) main_g = main_g || in.seg[sg].gV != nullptr;
+    if (radd && main_g) return false;
+    if (in.rseg.gV && (main_g || knn || in.rseg.g_r1 || in.rseg.g_r2 || !in.gidx)) return false;
+    for (int sg = 0; sg <= in.n_seg; ++sg) {
+      const pdr_seg_t& g = sg < in.n_seg ? in.seg[sg] : in.rseg;
       if (!g.gV) continue;
       if (in.gcnt) {
         if (g.g_zrow < 0 || !g.gV0) return false;
@@ -895,6 +925,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
 #define PDR_WS(RT, CT, WR, WC, KC)                            \
   do {                                                        \
     if (gath && knn) PDR_WS_K(RT, CT, WR, WC, KC, false, 2, false); \
+    else if (gath && radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 1, false);  \
     else if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, 1, false);  \
     else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, false); \
     else PDR_WS_K(RT, CT, WR, WC, KC, false, 0, false);       \
@@ -902,6 +933,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
 #define PDR_WS_SPLIT(RT, CT, WR, WC, KC)                      \
   do {                                                        \
     if (gath && knn) PDR_WS_K(RT, CT, WR, WC, KC, false, 2, true); \
+    else if (gath && radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 1, true);   \
     else if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, 1, true);   \
     else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, true); \
     else PDR_WS_K(RT, CT, WR, WC, KC, false, 0, true);        \

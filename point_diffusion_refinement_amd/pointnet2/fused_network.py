@@ -63,6 +63,10 @@ USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1
 # The same for the kNN (feature-propagation) blocks: consumers add the two per-position terms d2 r1 + w r2 in their
 # producer waves (GATH = 2 instantiations of the layer kernel).  PDR_VIRTUAL_KNN=0: materialised (A/B).
 USE_VIRTUAL_KNN = __import__("os").environ.get("PDR_VIRTUAL_KNN", "1") == "1"
+# The residual conv's columns of a virtual first conv (ball form) are not written either: the layer that adds the
+# residual gathers U_res[idx] + V_res in its producer waves (RADD + GATH instantiations of the layer kernel).
+# PDR_GATHER_RES=0: pdr_gather_add materialises them next to the statistics (A/B).
+GATHER_RES = __import__("os").environ.get("PDR_GATHER_RES", "1") == "1"
 # Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
 # FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
 # Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
@@ -718,7 +722,10 @@ class SplitFirstConv:
         # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
         # consumer, which stays a plain read) are written -- one pass
         Yres = None
-        if res is not None and res[0] % 4 == 0:
+        if res is not None and GATHER_RES and s1 is None:
+            res = None                        # consumers gather the residual window like any other
+            gather_add(None, ld, 0, -1)
+        elif res is not None and res[0] % 4 == 0:
             Yres = torch.empty((B * rpb, _pad4(res[1])), dtype=torch.float32, device=U.device)
             gather_add(Yres.data_ptr(), Yres.shape[1], res[0], res[1])
         else:

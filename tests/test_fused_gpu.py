@@ -128,7 +128,7 @@ def test_optional_fusions_match(cuda, monkeypatch):
     cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
     ts, label = torch.tensor([9.0, 4.0], device=cuda), torch.tensor([1, 7], device=cuda)
     base, _ = _cached_eps(net, fused, x, cond, ts, label)
-    for flag in ("FUSE_SCORE_POOL", "USE_VIRTUAL_FIRST", "USE_VIRTUAL_KNN"):
+    for flag in ("FUSE_SCORE_POOL", "USE_VIRTUAL_FIRST", "USE_VIRTUAL_KNN", "GATHER_RES"):
         default = getattr(FN, flag)
         for value in (True, False):
             monkeypatch.setattr(FN, flag, value)
@@ -391,7 +391,7 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
         x = t[:, :Cin].double()
         seg = (t.to(cuda), 0, Cin, ld, 1)
     pre, post = bool(seed & 1), bool(seed & 2)
-    has_ss, has_add, has_oadd = bool(seed & 4) or kind == "radd", bool(seed & 8), bool(seed & 16)
+    has_ss, has_add, has_oadd = bool(seed & 4) or kind in ("radd", "rgath"), bool(seed & 8), bool(seed & 16)
     scale = torch.randn(B, Cin, generator=g) if has_ss else None
     shift = torch.randn(B, Cin, generator=g) if has_ss else None
     add = torch.randn(B, Cin, generator=g) if has_add else None
@@ -408,6 +408,20 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
         rt = torch.randn(P, (Cin + 3) // 4 * 4, generator=g)
         x = x + rt[:, :Cin].double()
         radd = (rt.to(cuda), 0, Cin, rt.shape[1], 1)
+    if kind == "rgath":          # residual = a gathered first-conv window (ball form, 1/3 empty balls)
+        n_src, ldr = 3 * K, (Cin + 3) // 4 * 4 + 4
+        U = torch.randn(B * n_src + 1, ldr, generator=g)
+        U[-1] = 0
+        V2 = torch.randn(P // K, 2 * ldr, generator=g)
+        idx = torch.randint(0, n_src, (P,), generator=g, dtype=torch.int32)
+        cnt = torch.randint(0, 3, (P // K,), generator=g, dtype=torch.int32)
+        q = torch.arange(P) // K
+        rows = U[bidx * n_src + idx.long()][:, :Cin] + V2[q][:, :Cin]
+        x = x + torch.where((cnt[q] <= 0).unsqueeze(1), V2[q][:, ldr:ldr + Cin], rows).double()
+        V2c = V2.to(cuda)
+        radd = (U.to(cuda), 0, Cin, ldr, 1, {"V": (V2c, 0), "V0": (V2c, ldr), "ldv": 2 * ldr, "nsrc": n_src,
+                                              "zrow": B * n_src})
+        gidx = (idx.to(cuda), cnt.to(cuda))
     W = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
     bias = torch.randn(Cout, generator=g)
     ref = x @ W.t().double() + bias.double()
@@ -423,7 +437,7 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
     return act, _conv(W.to(cuda), bias.to(cuda)), ref
 
 
-@pytest.mark.parametrize("kind", ["plain", "radd", "gath"])
+@pytest.mark.parametrize("kind", ["plain", "radd", "gath", "rgath"])
 def test_narrow_layers_on_128_row_tiles(cuda, kind):
     """Tile variants 7 / 8 (128 rows, 32-channel chunks: the level-0 / level-1 narrow layers): channel counts that
     end inside a chunk, all prologue / epilogue options, more tiles than resident workgroups (persistent loop) with
@@ -453,6 +467,20 @@ def test_narrow_layers_on_128_row_tiles(cuda, kind):
             s2 = (f * f).view(B, rpb, Cout).sum(1)
             st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
             assert _rel(st[..., 0], s1) < 2e-4 and _rel(st[..., 1], s2) < 2e-4, (kind, B, rpb, Cin, Cout, seed)
+
+
+@pytest.mark.parametrize("B,rpb,Cin,Cout", [(2, 256, 128, 128), (3, 64, 256, 256), (2, 1024, 100, 140), (2, 384, 64, 96)])
+def test_gathered_residual_on_wide_tiles(cuda, B, rpb, Cin, Cout):
+    """A gathered residual (the residual conv of a virtual first conv) through the 128- / 64-row wide tiles and
+    through a shape without a wave-specialised instantiation (128 x 160: uniform-wave kernel)."""
+    for seed in (3, 12, 21):
+        act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, "rgath")
+        Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=Cout)
+        torch.cuda.synchronize()
+        got = Y[:, :Cout].double().cpu()
+        assert _rel(got, ref) < 5e-5, (B, rpb, Cin, Cout, seed, _rel(got, ref))
+        st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
+        assert _rel(st[..., 0], ref.view(B, rpb, Cout).sum(1)) < 2e-4
 
 
 @pytest.mark.timeout(300)
