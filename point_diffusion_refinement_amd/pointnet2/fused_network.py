@@ -65,8 +65,10 @@ USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1
 USE_VIRTUAL_KNN = __import__("os").environ.get("PDR_VIRTUAL_KNN", "1") == "1"
 # The residual conv's columns of a virtual first conv (ball form) are not written either: the layer that adds the
 # residual gathers U_res[idx] + V_res in its producer waves (RADD + GATH instantiations of the layer kernel).
-# PDR_GATHER_RES=0: pdr_gather_add materialises them next to the statistics (A/B).
-GATHER_RES = __import__("os").environ.get("PDR_GATHER_RES", "1") == "1"
+# Only for residuals of up to PDR_GATHER_RES channels (default 32; 0 = never): measured per layer alone on the chip,
+# 2 M x 32 -> 32 175 -> 160 us plus the saved 268 MB write, but 1 M x 64 -> 64 177 -> 274 us (a second 256-byte gather
+# per row and register spills in the producer waves) and 262144 x 128 -> 128 110 -> 138 us.
+GATHER_RES = int(__import__("os").environ.get("PDR_GATHER_RES", "32"))
 # Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
 # FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
 # Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
@@ -722,7 +724,7 @@ class SplitFirstConv:
         # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
         # consumer, which stays a plain read) are written -- one pass
         Yres = None
-        if res is not None and GATHER_RES and s1 is None:
+        if res is not None and res[1] <= GATHER_RES and s1 is None:
             res = None                        # consumers gather the residual window like any other
             gather_add(None, ld, 0, -1)
         elif res is not None and res[0] % 4 == 0:

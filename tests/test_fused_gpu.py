@@ -128,9 +128,10 @@ def test_optional_fusions_match(cuda, monkeypatch):
     cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
     ts, label = torch.tensor([9.0, 4.0], device=cuda), torch.tensor([1, 7], device=cuda)
     base, _ = _cached_eps(net, fused, x, cond, ts, label)
-    for flag in ("FUSE_SCORE_POOL", "USE_VIRTUAL_FIRST", "USE_VIRTUAL_KNN", "GATHER_RES"):
+    for flag, values in (("FUSE_SCORE_POOL", (True, False)), ("USE_VIRTUAL_FIRST", (True, False)),
+                         ("USE_VIRTUAL_KNN", (True, False)), ("GATHER_RES", (0, 32, 4096))):
         default = getattr(FN, flag)
-        for value in (True, False):
+        for value in values:
             monkeypatch.setattr(FN, flag, value)
             got, _ = _cached_eps(net, fused, x, cond, ts, label)
             assert ((got - base).abs() / (base.abs() + 1.0)).max() < 1e-3, (flag, value)
