@@ -39,12 +39,12 @@ def _b(x):
     return "true" if x else "false"
 
 
-def _layer_symbol(plan):
+def _layer_symbol(plan, pool=False):
     ws, vid, radd, gath, vec, split = plan
     t = ", ".join(str(v) for v in _VARIANT[vid])
     if ws:
-        return "fused_layer_ws_kernel<%s, %s, %d, %s>" % (t, _b(radd), int(gath), _b(split))
-    return "fused_layer_kernel<%s, %s, %s, %s, false>" % (t, _b(radd), _b(vec), _b(gath))
+        return "fused_layer_ws_kernel<%s, %s, %d, %s, %s>" % (t, _b(radd), int(gath), _b(split), _b(pool))
+    return "fused_layer_kernel<%s, %s, %s, %s, %s>" % (t, _b(radd), _b(vec), _b(gath), _b(pool))
 
 
 def _work(name, args, lib):
@@ -75,6 +75,15 @@ def _work(name, args, lib):
         if li.rseg.ptr:
             byt += 4.0 * P * Cin
         return _layer_symbol((1, vid, bool(li.rseg.ptr), gath, 1, 1)), 2.0 * P * Cin * Cout, byt
+    if name == "pdr_fused_layer_pool":
+        # scores = layer(in) stay in the accumulators; read: layer input + value rows, written: pooled rows
+        li = args[0]._obj
+        P, Cin, D, K = args[1], args[2], args[6], args[13]
+        vid = lib.pdr_fused_layer_variant(li.rows_per_batch, D)
+        tm = lib.pdr_fused_layer_tile_rows(li.rows_per_batch, D)
+        ws = int(li.rows_per_batch % tm == 0 and vid not in (3, 6))
+        byt = 4.0 * P * (Cin + D) + 4.0 * (P // K) * D
+        return _layer_symbol((ws, vid, False, 0, 1, 0), pool=True), 2.0 * P * Cin * D, byt
     if name == "pdr_gather_add":
         ldu, n_src, B, rpb, K, Cout, Y, ycols = args[1], args[2], args[12], args[13], args[14], args[15], args[16], args[21]
         P = B * rpb
@@ -88,9 +97,9 @@ def _work(name, args, lib):
     return name.replace("pdr_", "") + " (C ABI)", 0.0, 0.0
 
 
-_TIMED = ("pdr_fused_layer", "pdr_fused_layer_bf16x3", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
+_TIMED = ("pdr_fused_layer", "pdr_fused_layer_bf16x3", "pdr_fused_layer_pool", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
           "pdr_furthest_point_sampling", "pdr_ball_query", "pdr_knn_points", "pdr_group_build", "pdr_knn_build",
-          "pdr_fused_layer_pool", "pdr_knn_weights", "pdr_pad_rows")
+          "pdr_knn_weights", "pdr_pad_rows")
 
 
 def latest_traffic_file():
@@ -163,7 +172,9 @@ def step_kernel_table(sampler, reps=3, overlapped=False):
 
 def _roof(flops, byt, ms, symbol):
     # split mode: three bf16 MFMAs per algorithmic product -> a third of the dense bf16 peak
-    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if symbol.endswith(", true>") else FP32_MFMA_PEAK_TFLOPS
+    args = symbol[symbol.find("<") + 1:symbol.rfind(">")].split(", ") if "<" in symbol else []
+    split = symbol.startswith("fused_layer_ws_kernel") and len(args) >= 8 and args[7] == "true"
+    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
     t_mfma = flops / (peak_tf * 1e12)
     t_hbm = byt / (HBM_PEAK_GBS * 1e9)
     if t_mfma >= t_hbm and flops > 0:

@@ -25,11 +25,14 @@ def main():
     t0 = min(c[0, 0], p[0, 0])
     print("chunk | consumer: wait  compute  epi | producer: loadwait  commit  fetch-issue | c.period | p.arrive-c.arrive")
     e = buf[2].reshape(-1, 8).astype(np.int64)
-    nch = 4
-    print("epilogue checkpoints per tile (ticks after the last MFMA issue): after column tile 0, 1, ..., before ticket")
+    rpb, Cin, Cout = FB.SHAPES[idx]
+    kc = 16 if (lib.pdr_fused_layer_variant(rpb, Cout) in (0, 1)) else 32
+    nch = (Cin + kc - 1) // kc
+    print("epilogue checkpoints per tile (ticks after the last MFMA issue; slot 0: end of column tile 0, 1: Tt writes of "
+          "half 0, 2: statistics of half 0, 3 / 4: stores of half 0 / 1, 6: before the ticket; c3 = end of epilogue)")
     for t in range(min(6, n // nch)):
         base = c[t * nch + nch - 1, 2]
-        print("  tile %d:" % t, [int(x - base) for x in e[t] if x > 0])
+        print("  tile %d:" % t, {k: int(x - base) for k, x in enumerate(e[t]) if x > 0}, "end", int(c[t * nch + nch - 1, 3] - base))
     for g in range(min(n, 70)):
         per = c[g + 1, 0] - c[g, 0] if g + 1 < n else 0
         print("%4d | %6d %6d %6d | %6d %6d %6d | %6d | %d" % (
