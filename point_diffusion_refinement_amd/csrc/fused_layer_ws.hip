@@ -167,6 +167,14 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     const float lo_post = in.post_relu ? 0.0f : -__builtin_inff();
     const int pt = tid - 256;
     const int vc4 = pt % C4, vr0 = pt / C4;
+    // Rows of this thread.  Plain variants: vr0 + VSTEP i (a wave's load instruction covers 64 / C4 consecutive rows).
+    // Gathered variants (ROWQ): APT4 CONSECUTIVE rows APT4 vr0 + i -- they belong to ONE query (APT4 divides K), so
+    // the query row V, the ball count and the empty-ball decision are loaded / taken once per thread and tile, and
+    // the APT4 neighbour indices are one vector load: 20 -> 11 vector-memory instructions per thread and tile (the
+    // gathered narrow layers are bound by the CU's vector-memory issue, not by bytes or latency).
+    constexpr bool ROWQ = GATH != 0;
+    const int gsh_ = GATH ? __builtin_ctz(in.gK) : 0;
+    auto prow = [&](int i) __attribute__((always_inline)) -> int { return ROWQ ? APT4 * vr0 + i : vr0 + VSTEP * i; };
     const int ss_ld = in.ss_ld > 0 ? in.ss_ld : Cin;
     const bool has_pre = in.pre_relu != 0, has_add = in.add != nullptr;
     // per-thread byte offsets that do not change from chunk to chunk (full tiles, full chunks): the
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       if constexpr (RADD) {
 #pragma unroll
         for (int i = 0; i < APT4; ++i)
-          r_off[i] = static_cast<unsigned>((vr0 + VSTEP * i) * in.rseg.ld + 4 * vc4) * 4u;
+          r_off[i] = static_cast<unsigned>(prow(i) * in.rseg.ld + 4 * vc4) * 4u;
       }
     }
     // GATHERED sources (first conv of a grouped block consumed without materialising it, see
@@ -192,8 +200,22 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // Per tile: this thread's neighbour indices (-1 = empty ball); per (tile, segment): byte offsets.
     // (the kNN form has no ball counts and, for the sake of its register budget -- two more per-position values and
     // two more row quads live in the producer -- no next-tile index prefetch)
-    int g_idx[GATH ? APT4 : 1], n_idx[GATH == 1 ? APT4 : 1], n_cnt[GATH == 1 ? APT4 : 1];
-    unsigned v_off[GATH ? APT4 : 1];
+    int g_idx[GATH ? APT4 : 1], n_idx[GATH == 1 ? APT4 : 1], n_cnt = 1;
+    unsigned v_off = 0;
+    // neighbour indices of this thread's APT4 consecutive rows of the tile starting at r0 (nv valid rows) + the
+    // ball count of their query: one vector load + one dword load for whole tiles
+    auto load_idx = [&](long r0, int nv, int (&id)[GATH ? APT4 : 1], int& cnt) __attribute__((always_inline)) {
+      if constexpr (GATH != 0) {
+        const int rf = min(APT4 * vr0, nv - 1);
+        cnt = in.gcnt ? in.gcnt[(r0 + rf) >> gsh_] : 1;
+        if (nv == TM) {                                  // uniform
+          __builtin_memcpy(&id[0], in.gidx + r0 + APT4 * vr0, sizeof(int) * APT4);
+        } else {
+#pragma unroll
+          for (int i = 0; i < APT4; ++i) id[i] = in.gidx[r0 + min(APT4 * vr0 + i, nv - 1)];
+        }
+      }
+    };
     constexpr bool KNN = GATH == 2;
     float gs1v[KNN ? APT4 : 1], gs2v[KNN ? APT4 : 1];   // per tile: d2 / weight of this thread's positions
     f32x4 Rq1, Rq2;                                      // per chunk: the conv rows of those two channels
@@ -204,8 +226,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // RG: the RESIDUAL is a gathered first-conv window (U_res[idx] + V_res: the residual conv of a block whose
     // first conv is virtual) -- the main sources are plain then
     constexpr bool RG = RADD && GATH == 1;
-    float4 Rrv[APT4], Rrv2[GATH ? APT4 : 1];
-    f32x4 Rrrv[RADD ? APT4 : 1], Rrrv2[RG ? APT4 : 1];   // (vector values: conditional float4 struct copies go through scratch)
+    float4 Rrv[APT4], Rrv2[1];
+    f32x4 Rrrv[RADD ? APT4 : 1], Rrrv2[1];   // (vector values: conditional float4 struct copies go through scratch)
     f32x4 Rrw[WPT4];
     float Rps[4], Rph[4], Rpa[4];
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
@@ -229,23 +251,25 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             // indices prefetched while the previous tile's last chunk was fetched: the dependent
             // index -> row load chain is off the per-tile critical path
 #pragma unroll
-            for (int i = 0; i < APT4; ++i) g_idx[i] = n_cnt[i] <= 0 ? -1 : n_idx[i];
+            for (int i = 0; i < APT4; ++i) g_idx[i] = n_cnt <= 0 ? -1 : n_idx[i];
           } else {
+            int cnt = 1;
+            load_idx(row0, nvalid, g_idx, cnt);
 #pragma unroll
-            for (int i = 0; i < APT4; ++i) {
-              const long p = row0 + min(vr0 + VSTEP * i, nvalid - 1);
-              const int id = in.gidx[p];
-              const int cnt = in.gcnt ? in.gcnt[p >> gsh] : 1;
-              g_idx[i] = cnt <= 0 ? -1 : id;
-            }
+            for (int i = 0; i < APT4; ++i) g_idx[i] = cnt <= 0 ? -1 : g_idx[i];
           }
           if constexpr (KNN) {
             // consumed at the commit of this tile's first chunk, one chunk period from now: no prefetch needed
+            if (nvalid == TM) {                          // uniform: one vector load per array
+              __builtin_memcpy(&gs1v[0], in.gs1 + row0 + APT4 * vr0, sizeof(float) * APT4);
+              __builtin_memcpy(&gs2v[0], in.gs2 + row0 + APT4 * vr0, sizeof(float) * APT4);
+            } else {
 #pragma unroll
-            for (int i = 0; i < APT4; ++i) {
-              const long p = row0 + min(vr0 + VSTEP * i, nvalid - 1);
-              gs1v[i] = in.gs1[p];
-              gs2v[i] = in.gs2[p];
+              for (int i = 0; i < APT4; ++i) {
+                const long p = row0 + min(prow(i), nvalid - 1);
+                gs1v[i] = in.gs1[p];
+                gs2v[i] = in.gs2[p];
+              }
             }
           }
           g_tile = c.tile;
@@ -255,12 +279,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           const int nb = nt / tpb, ntb = nt - nb * tpb;
           const long nrow0 = static_cast<long>(nb) * rpb + static_cast<long>(ntb) * TM;
           const int nnv = min(TM, rpb - ntb * TM);
-#pragma unroll
-          for (int i = 0; i < APT4; ++i) {
-            const long p = nrow0 + min(vr0 + VSTEP * i, nnv - 1);
-            n_idx[i] = in.gidx[p];
-            n_cnt[i] = in.gcnt ? in.gcnt[p >> gsh] : 1;
-          }
+          if constexpr (GATH == 1) load_idx(nrow0, nnv, n_idx, n_cnt);
           n_tile = nt;
         }
       }
@@ -273,28 +292,25 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       const char* wb = SPLIT ? reinterpret_cast<const char*>(Wt) +
                                    (static_cast<long>(blockIdx.y) * ldw + c.ci) * (2L * TN * 64)
                              : reinterpret_cast<const char*>(Wt + static_cast<long>(c.cbase + c.ks) * ldw + n0);
-      unsigned ao[APT4], ro[RADD ? APT4 : 1], wo[WPT4], po[4], vo[GATH ? APT4 : 1];
+      unsigned ao[APT4], ro[RADD ? APT4 : 1], wo[WPT4], po[4], vo = 0;
       if (Rkmax == KC && nvalid == TM) {
         // ---- fast path (uniform): the precomputed per-thread offsets
         if (off_sg != c.sg) {
           off_sg = c.sg;
 #pragma unroll
           for (int i = 0; i < APT4; ++i) {
-            int row = (vr0 + VSTEP * i) >> shift;
+            int row = prow(i) >> shift;
             if constexpr (GATH) {
               if (f_g) {
                 row = g_idx[i] < 0 ? zrow : g_idx[i];
-                v_off[i] = static_cast<unsigned>(((vr0 + VSTEP * i) >> gsh) * seg.g_ldv + 4 * vc4 +
-                                                 (g_idx[i] < 0 ? v0d : 0)) * 4u;
+                if (i == 0)
+                  v_off = static_cast<unsigned>((prow(0) >> gsh) * seg.g_ldv + 4 * vc4 + (g_idx[0] < 0 ? v0d : 0)) * 4u;
               }
             }
             a_off[i] = static_cast<unsigned>(row * seg.ld + 4 * vc4) * 4u;
           }
         }
-        if constexpr (GATH) {
-#pragma unroll
-          for (int i = 0; i < APT4; ++i) vo[i] = v_off[i];
-        }
+        if constexpr (GATH) vo = v_off;
         Rcvalid = 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) po[j] = 16u * vc4 + 4u * j;
@@ -316,12 +332,12 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
 #pragma unroll
         for (int i = 0; i < APT4; ++i) {
           // rows beyond nvalid re-read the tile's last row; masked in the epilogue
-          const int r = min(vr0 + VSTEP * i, nvalid - 1);
+          const int r = min(prow(i), nvalid - 1);
           int row = r >> shift;
           if constexpr (GATH) {
             if (f_g) {
               row = g_idx[i] < 0 ? zrow : g_idx[i];
-              vo[i] = static_cast<unsigned>((r >> gsh) * seg.g_ldv + clc + (g_idx[i] < 0 ? v0d : 0)) * 4u;
+              if (i == 0) vo = static_cast<unsigned>((r >> gsh) * seg.g_ldv + clc + (g_idx[0] < 0 ? v0d : 0)) * 4u;
             }
           }
           ao[i] = static_cast<unsigned>(row * seg.ld + clc) * 4u;
@@ -363,9 +379,9 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       if constexpr (GATH) {
         Rgath = f_g;
         if (f_g) {
+          // ONE query row per thread: its APT4 consecutive rows belong to the same query
           const char* vb = reinterpret_cast<const char*>(seg.gV + (row0 >> gsh) * seg.g_ldv + c.ks);
-#pragma unroll
-          for (int i = 0; i < APT4; ++i) Rrv2[i] = *reinterpret_cast<const float4*>(vb + vo[i]);
+          Rrv2[0] = *reinterpret_cast<const float4*>(vb + vo);
           if constexpr (KNN) {
             // this thread's four channels of the d2 / weight rows (4-byte aligned in general; the column
             // offset stays inside the segment's 4-padded width, as for the A loads)
@@ -389,12 +405,12 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
         const int colq = fast ? 4 * vc4 : min(4 * vc4, ((Cin + 3) & ~3) - 4 - c.cbase - c.ks);
 #pragma unroll
         for (int i = 0; i < APT4; ++i) {
-          const int r = min(vr0 + VSTEP * i, nvalid - 1);
           const int urow = g_idx[i] < 0 ? rz : g_idx[i];
           Rrrv[i] = *reinterpret_cast<const f32x4*>(rb + static_cast<unsigned>(urow * rs_ld + colq) * 4u);
-          Rrrv2[i] = *reinterpret_cast<const f32x4*>(
-              rvb + static_cast<unsigned>((r >> gsh) * rs_ldv + colq + (g_idx[i] < 0 ? rv0d : 0)) * 4u);
         }
+        Rrrv2[0] = *reinterpret_cast<const f32x4*>(
+            rvb + static_cast<unsigned>((min(prow(0), nvalid - 1) >> gsh) * rs_ldv + colq +
+                                        (g_idx[0] < 0 ? rv0d : 0)) * 4u);
       } else if constexpr (RADD) {
         const char* rb = reinterpret_cast<const char*>(in.rseg.ptr + row0 * in.rseg.ld + c.cbase + c.ks);
 #pragma unroll
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           float x[4] = {Rrv[i].x, Rrv[i].y, Rrv[i].z, Rrv[i].w};
           if constexpr (GATH) {
             if (Rgath) {   // uniform: neighbour row + query row
-              x[0] += Rrv2[i].x; x[1] += Rrv2[i].y; x[2] += Rrv2[i].z; x[3] += Rrv2[i].w;
+              x[0] += Rrv2[0].x; x[1] += Rrv2[0].y; x[2] += Rrv2[0].z; x[3] += Rrv2[0].w;
               if constexpr (KNN) {   // + d2 r1 + w r2, in pdr_gather_add's order (same bits as its statistics saw)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           if constexpr (RADD) {
             q[0] = Rrrv[i][0]; q[1] = Rrrv[i][1]; q[2] = Rrrv[i][2]; q[3] = Rrrv[i][3];
             if constexpr (RG) {   // neighbour row + query row, as pdr_gather_add would have written them
-              q[0] += Rrrv2[i][0]; q[1] += Rrrv2[i][1]; q[2] += Rrrv2[i][2]; q[3] += Rrrv2[i][3];
+              q[0] += Rrrv2[0][0]; q[1] += Rrrv2[0][1]; q[2] += Rrrv2[0][2]; q[3] += Rrrv2[0][3];
             }
           }
 #pragma unroll
@@ -447,8 +463,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             x[j] = v;
           }
           if constexpr (!SPLIT) {
-            *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4][vr0 + VSTEP * i][0]) = f32x2{x[0], x[1]};
-            *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4 + 1][vr0 + VSTEP * i][0]) = f32x2{x[2], x[3]};
+            *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4][prow(i)][0]) = f32x2{x[0], x[1]};
+            *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4 + 1][prow(i)][0]) = f32x2{x[2], x[3]};
           }
           if constexpr (SPLIT) {
             // x = hi + lo + O(2^-17 |x|): hi = bf16(x) (round to nearest even), lo = bf16(x - hi); the four
@@ -458,7 +474,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             const bf16x2 h01 = __builtin_convertvector(v01, bf16x2), h23 = __builtin_convertvector(v23, bf16x2);
             const f2 r01 = v01 - __builtin_convertvector(h01, f2), r23 = v23 - __builtin_convertvector(h23, f2);
             const bf16x2 l01 = __builtin_convertvector(r01, bf16x2), l23 = __builtin_convertvector(r23, bf16x2);
-            const int r = vr0 + VSTEP * i;
+            const int r = prow(i);
             const int off = split_off(r, vc4 >> 1) + ((vc4 & 1) << 3);
             typedef unsigned u2 __attribute__((ext_vector_type(2)));
             *reinterpret_cast<u2*>(&sm.A[st][0][off]) =
@@ -882,6 +898,7 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
     // gathered sources here: either the main sources (plain residual or none) or the residual alone (ball form);
     // empty balls through the table's zero row and a V0 that sits a small non-negative offset behind V (one
     // allocation)
+    if (in.gK < 4) return false;   // a producer thread's 2 or 4 consecutive rows share one query
     bool main_g = false;
     for (int sg = 0; sg < in.n_seg; ++sg) main_g = main_g || in.seg[sg].gV != nullptr;
     if (radd && main_g) return false;

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="zero operands (DVFS probe: data-dependent power)")
     ap.add_argument("--only", type=int, default=None, help="index into SHAPES")
     ap.add_argument("--first", type=int, default=0, help="skip SHAPES before this index")
+    ap.add_argument("--gath", type=int, default=0, help="K > 0: the source is a gathered first conv (U[idx] + V, K "
+                                                         "neighbours per query, 2048 source points per cloud)")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = args.lib
@@ -55,6 +57,17 @@ def main():
         li = _lib.LayerIn()
         li.n_seg = 1
         li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, ldx, 1
+        if args.gath:
+            K, n_src = args.gath, 2048
+            U = torch.randn(B * n_src + 1, ldx, device=dev)
+            V2 = torch.randn(P // K, 2 * ldx, device=dev)
+            # neighbours of a query are close in index (ball queries on FPS-ordered clouds are not, but share lines)
+            idx = torch.randint(0, n_src, (P,), device=dev, dtype=torch.int32)
+            cnt = torch.full((P // K,), K, device=dev, dtype=torch.int32)
+            li.seg[0].ptr = U.data_ptr()
+            li.seg[0].gV, li.seg[0].gV0 = V2.data_ptr(), V2.data_ptr() + 4 * ldx
+            li.seg[0].g_ldv, li.seg[0].g_nsrc, li.seg[0].g_zrow = 2 * ldx, n_src, B * n_src
+            li.gidx, li.gcnt, li.gK = idx.data_ptr(), cnt.data_ptr(), K
         li.scale, li.shift = scale.data_ptr(), shift.data_ptr()
         li.pre_relu, li.post_relu, li.rows_per_batch = 0, 1, rpb
 

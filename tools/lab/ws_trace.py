@@ -14,7 +14,8 @@ def main():
     idx = int(sys.argv[1]) if len(sys.argv) > 1 else 13
     _lib.LIB_PATH = __import__("os").environ.get("PDR_LAB_LIB", "point_diffusion_refinement_amd/libpdr_lab.so")
     lib = _lib.load()
-    sys.argv = [sys.argv[0], "--only", str(idx), "--reps", "1", "--lib", _lib.LIB_PATH]
+    extra = sys.argv[2:]                                  # e.g. --gath 32
+    sys.argv = [sys.argv[0], "--only", str(idx), "--reps", "1", "--lib", _lib.LIB_PATH] + extra
     FB.main()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     buf = np.zeros((3, 4096), dtype=np.uint64)
