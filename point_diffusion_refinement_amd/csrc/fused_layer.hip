@@ -851,6 +851,7 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   }
   bool knn = false;
   for (int sg = 0; sg < in->n_seg; ++sg) knn = knn || in->seg[sg].g_r1 || in->seg[sg].g_r2;
+  knn = knn || (in->rseg.gV && (in->rseg.g_r1 || in->rseg.g_r2));
   pl->knn = knn;
   pl->vec = vec;
   pl->gath = gath;

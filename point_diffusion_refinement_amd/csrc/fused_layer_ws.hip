@@ -225,9 +225,9 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     // one chunk in registers (plain arrays: as members of a struct one W quad ended up in scratch)
     // RG: the RESIDUAL is a gathered first-conv window (U_res[idx] + V_res: the residual conv of a block whose
     // first conv is virtual) -- the main sources are plain then
-    constexpr bool RG = RADD && GATH == 1;
+    constexpr bool RG = RADD && GATH != 0;
     float4 Rrv[APT4], Rrv2[1];
-    f32x4 Rrrv[RADD ? APT4 : 1], Rrrv2[1];   // (vector values: conditional float4 struct copies go through scratch)
+    f32x4 Rrrv[RADD ? APT4 : 1], Rrrv2[1], Rqr1, Rqr2;   // Rqr: kNN-form residual, rows of the d2 / weight channels   // (vector values: conditional float4 struct copies go through scratch)
     f32x4 Rrw[WPT4];
     float Rps[4], Rph[4], Rpa[4];
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
@@ -411,6 +411,10 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
         Rrrv2[0] = *reinterpret_cast<const f32x4*>(
             rvb + static_cast<unsigned>((min(prow(0), nvalid - 1) >> gsh) * rs_ldv + colq +
                                         (g_idx[0] < 0 ? rv0d : 0)) * 4u);
+        if constexpr (GATH == 2) {
+          __builtin_memcpy(&Rqr1, in.rseg.g_r1 + c.cbase + c.ks + colq, 16);
+          __builtin_memcpy(&Rqr2, in.rseg.g_r2 + c.cbase + c.ks + colq, 16);
+        }
       } else if constexpr (RADD) {
         const char* rb = reinterpret_cast<const char*>(in.rseg.ptr + row0 * in.rseg.ld + c.cbase + c.ks);
 #pragma unroll
@@ -449,6 +453,13 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
             q[0] = Rrrv[i][0]; q[1] = Rrrv[i][1]; q[2] = Rrrv[i][2]; q[3] = Rrrv[i][3];
             if constexpr (RG) {   // neighbour row + query row, as pdr_gather_add would have written them
               q[0] += Rrrv2[0][0]; q[1] += Rrrv2[0][1]; q[2] += Rrrv2[0][2]; q[3] += Rrrv2[0][3];
+              if constexpr (GATH == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  q[j] = __builtin_fmaf(gs1v[i], Rqr1[j], q[j]);
+                  q[j] = __builtin_fmaf(gs2v[i], Rqr2[j], q[j]);
+                }
+              }
             }
           }
 #pragma unroll
@@ -888,12 +899,14 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
   if (id == 3 || id == 6 || id > 8) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
+  const bool knn_res = in.rseg.gV && in.rseg.g_r1;
   if (knn) {
     // kNN-form gathered sources: both per-position arrays, both rows on every gathered segment, no empty balls
     if (!gath || radd || !in.gs1 || !in.gs2 || in.gcnt) return false;
     for (int sg = 0; sg < in.n_seg; ++sg)
       if (in.seg[sg].gV && (!in.seg[sg].g_r1 || !in.seg[sg].g_r2)) return false;
   }
+  if (knn_res && (!in.gs1 || !in.gs2 || in.gcnt || !in.rseg.g_r2)) return false;   // kNN-form gathered residual
   if (gath) {
     // gathered sources here: either the main sources (plain residual or none) or the residual alone (ball form);
     // empty balls through the table's zero row and a V0 that sits a small non-negative offset behind V (one
@@ -902,7 +915,7 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
     bool main_g = false;
     for (int sg = 0; sg < in.n_seg; ++sg) main_g = main_g || in.seg[sg].gV != nullptr;
     if (radd && main_g) return false;
-    if (in.rseg.gV && (main_g || knn || in.rseg.g_r1 || in.rseg.g_r2 || !in.gidx)) return false;
+    if (in.rseg.gV && (main_g || knn || !in.gidx)) return false;
     for (int sg = 0; sg <= in.n_seg; ++sg) {
       const pdr_seg_t& g = sg < in.n_seg ? in.seg[sg] : in.rseg;
       if (!g.gV) continue;
@@ -939,9 +952,11 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
                      in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
+  const bool knn_res = in.rseg.gV && in.rseg.g_r1;
 #define PDR_WS(RT, CT, WR, WC, KC)                            \
   do {                                                        \
     if (gath && knn) PDR_WS_K(RT, CT, WR, WC, KC, false, 2, false); \
+    else if (gath && radd && knn_res) PDR_WS_K(RT, CT, WR, WC, KC, true, 2, false);  \
     else if (gath && radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 1, false);  \
     else if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, 1, false);  \
     else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, false); \
@@ -950,6 +965,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
 #define PDR_WS_SPLIT(RT, CT, WR, WC, KC)                      \
   do {                                                        \
     if (gath && knn) PDR_WS_K(RT, CT, WR, WC, KC, false, 2, true); \
+    else if (gath && radd && knn_res) PDR_WS_K(RT, CT, WR, WC, KC, true, 2, true);   \
     else if (gath && radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 1, true);   \
     else if (gath) PDR_WS_K(RT, CT, WR, WC, KC, false, 1, true);   \
     else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, true); \

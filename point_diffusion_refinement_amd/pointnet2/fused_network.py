@@ -65,10 +65,11 @@ USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1
 USE_VIRTUAL_KNN = __import__("os").environ.get("PDR_VIRTUAL_KNN", "1") == "1"
 # The residual conv's columns of a virtual first conv (ball form) are not written either: the layer that adds the
 # residual gathers U_res[idx] + V_res in its producer waves (RADD + GATH instantiations of the layer kernel).
-# Only for residuals of up to PDR_GATHER_RES channels (default 32; 0 = never): measured per layer alone on the chip,
-# 2 M x 32 -> 32 175 -> 160 us plus the saved 268 MB write, but 1 M x 64 -> 64 177 -> 274 us (a second 256-byte gather
-# per row and register spills in the producer waves) and 262144 x 128 -> 128 110 -> 138 us.
-GATHER_RES = int(__import__("os").environ.get("PDR_GATHER_RES", "32"))
+# For residual windows of up to PDR_GATHER_RES channels (default: all; 0 = never).  Same box, graph replay: 9.35 ms per
+# step gathering only the 32-channel residuals, 9.24 up to 64, 9.20 all of them (ball form; with four query-row loads
+# per thread the wider kernels had spilled registers and lost).
+GATHER_RES = int(__import__("os").environ.get("PDR_GATHER_RES", "4096"))
+GATHER_RES_KNN = __import__("os").environ.get("PDR_GATHER_RES_KNN", "1") == "1"    # the kNN (FP) blocks' residuals too
 # Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
 # FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
 # Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
@@ -240,13 +241,14 @@ SIDE_TABLES = __import__("os").environ.get("PDR_SIDE_TABLES", "0") == "1"
 _PAR = {"stream": None}
 PAR_DEEP = __import__("os").environ.get("PDR_PAR_DEEP", "1") == "1"
 PAR_MAX_ROWS = int(__import__("os").environ.get("PDR_PAR_MAX_ROWS", str(1 << 40)))
+PAR_MIN_ROWS = int(__import__("os").environ.get("PDR_PAR_MIN_ROWS", "0"))     # (A/B: fork only blocks of >= this many rows)
 
 
 def _fork_join(rows, chain_a):
     """Run `chain_a()` on the auxiliary stream if this block qualifies; returns a thunk that joins and yields its
     result (or the result itself when everything stays on the current stream)."""
     aux = _PAR["stream"]
-    if aux is None or rows > PAR_MAX_ROWS:
+    if aux is None or rows > PAR_MAX_ROWS or rows < PAR_MIN_ROWS:
         return chain_a()
     main = torch.cuda.current_stream()
     fork = torch.cuda.Event()
@@ -354,10 +356,12 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
         if rc == _lib.PDR_EUNSUPPORTED and act.gs1 is not None and act.first is not None:
             # a kNN-form gathered source reached a tile shape without a wave-specialised kernel: materialise the
             # columns it reads (one pdr_gather_add window per segment) and run the layer on plain sources
-            segs = [(act.first.materialise(sg[1], sg[2]), 0, sg[2], _pad4(sg[2]), 1) if len(sg) > 5 and sg[5] else sg
-                    for sg in act.segs]
+            def dense(sg):
+                return (act.first.materialise(sg[1], sg[2]), 0, sg[2], _pad4(sg[2]), 1) if len(sg) > 5 and sg[5] else sg
+            segs = [dense(sg) for sg in act.segs]
             plain_act = Act(segs, act.P, act.B, act.rpb, scale=act.scale, shift=act.shift, add=act.add,
-                            add_ld=act.add_ld, radd=act.radd, pre_relu=act.pre_relu, post_relu=act.post_relu)
+                            add_ld=act.add_ld, radd=None if act.radd is None else dense(act.radd),
+                            pre_relu=act.pre_relu, post_relu=act.post_relu)
             plain_act.ss_ld, plain_act.oadd = act.ss_ld, act.oadd
             li = plain_act.struct()
             rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
@@ -724,7 +728,7 @@ class SplitFirstConv:
         # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
         # consumer, which stays a plain read) are written -- one pass
         Yres = None
-        if res is not None and res[1] <= GATHER_RES and s1 is None:
+        if res is not None and res[1] <= GATHER_RES and (s1 is None or GATHER_RES_KNN):
             res = None                        # consumers gather the residual window like any other
             gather_add(None, ld, 0, -1)
         elif res is not None and res[0] % 4 == 0:
@@ -843,7 +847,7 @@ class FusedGroupedBlock:
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
         B, m, _ = new_xyz.shape
         K = self.nsample
-        if not (USE_SPLIT_FIRST and _PAR["stream"] is not None and B * m * K <= PAR_MAX_ROWS):
+        if not (USE_SPLIT_FIRST and _PAR["stream"] is not None and PAR_MIN_ROWS <= B * m * K <= PAR_MAX_ROWS):
             return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh, V2=V2),
                                query_feats_cl)
         # deep level: first GEMM here, then [MLP + value conv] on the auxiliary stream beside [query / score convs]
@@ -889,7 +893,7 @@ class FusedKnnFP:
                 known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0, s1=d2, s2=wgt, V2=V2,
                 virtual=USE_VIRTUAL_FIRST and USE_VIRTUAL_KNN,
                 res=(self.mlp1.res_col0, self.mlp1.Clast) if self.mlp1.res_col0 is not None else None)
-            if _PAR["stream"] is not None and B * n * K <= PAR_MAX_ROWS:
+            if _PAR["stream"] is not None and PAR_MIN_ROWS <= B * n * K <= PAR_MAX_ROWS:
                 def chain_a():
                     hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
                     return self.att.values(hh, B, n, K)

@@ -129,7 +129,8 @@ def test_optional_fusions_match(cuda, monkeypatch):
     ts, label = torch.tensor([9.0, 4.0], device=cuda), torch.tensor([1, 7], device=cuda)
     base, _ = _cached_eps(net, fused, x, cond, ts, label)
     for flag, values in (("FUSE_SCORE_POOL", (True, False)), ("USE_VIRTUAL_FIRST", (True, False)),
-                         ("USE_VIRTUAL_KNN", (True, False)), ("GATHER_RES", (0, 32, 4096))):
+                         ("USE_VIRTUAL_KNN", (True, False)), ("GATHER_RES", (0, 32, 4096)),
+                         ("GATHER_RES_KNN", (True, False))):
         default = getattr(FN, flag)
         for value in values:
             monkeypatch.setattr(FN, flag, value)
@@ -392,7 +393,7 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
         x = t[:, :Cin].double()
         seg = (t.to(cuda), 0, Cin, ld, 1)
     pre, post = bool(seed & 1), bool(seed & 2)
-    has_ss, has_add, has_oadd = bool(seed & 4) or kind in ("radd", "rgath"), bool(seed & 8), bool(seed & 16)
+    has_ss, has_add, has_oadd = bool(seed & 4) or kind in ("radd", "rgath", "rknn"), bool(seed & 8), bool(seed & 16)
     scale = torch.randn(B, Cin, generator=g) if has_ss else None
     shift = torch.randn(B, Cin, generator=g) if has_ss else None
     add = torch.randn(B, Cin, generator=g) if has_add else None
@@ -423,6 +424,24 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
         radd = (U.to(cuda), 0, Cin, ldr, 1, {"V": (V2c, 0), "V0": (V2c, ldr), "ldv": 2 * ldr, "nsrc": n_src,
                                               "zrow": B * n_src})
         gidx = (idx.to(cuda), cnt.to(cuda))
+    knn = None
+    if kind == "rknn":           # residual = a gathered first-conv window, kNN form (+ s1 r1 + s2 r2, no empty balls)
+        n_src, ldr = 3 * K, (Cin + 3) // 4 * 4 + 4
+        U = torch.randn(B * n_src + 1, ldr, generator=g)
+        V2 = torch.randn(P // K, ldr, generator=g)
+        idx = torch.randint(0, n_src, (P,), generator=g, dtype=torch.int32)
+        s1, s2 = torch.rand(P, generator=g), torch.rand(P, generator=g)
+        r1, r2 = torch.randn(ldr + 4, generator=g), torch.randn(ldr + 4, generator=g)
+        q = torch.arange(P) // K
+        rows = U[bidx * n_src + idx.long()][:, :Cin] + V2[q][:, :Cin]
+        rows = rows + s1[:, None] * r1[None, :Cin] + s2[:, None] * r2[None, :Cin]
+        x = x + rows.double()
+        knn = (s1.to(cuda), s2.to(cuda), r1.to(cuda), r2.to(cuda))
+        radd = (U.to(cuda), 0, Cin, ldr, 1, {"V": (V2.to(cuda), 0), "V0": None, "ldv": ldr, "nsrc": n_src,
+                                              "zrow": B * n_src, "r1": (knn[2], 0), "r2": (knn[3], 0)})
+        gidx = (idx.to(cuda), None)
+        dense = torch.zeros(P, (Cin + 3) // 4 * 4)
+        dense[:, :Cin] = rows
     W = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
     bias = torch.randn(Cout, generator=g)
     ref = x @ W.t().double() + bias.double()
@@ -431,6 +450,10 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
                  add_ld=Cin, radd=radd, pre_relu=pre, post_relu=post)
     if gidx is not None:
         act.gidx, act.gcnt, act.gK = gidx[0], gidx[1], K
+    if knn is not None:
+        act.gs1, act.gs2 = knn[0], knn[1]
+        # what SplitFirstConv hands consumers without a kNN-gathering kernel (run_layer's fallback)
+        act.first = type("First", (), {"materialise": staticmethod(lambda col0, C: dense.to(cuda))})
     if has_oadd:
         od = torch.randn(P // K, (Cout + 3) // 4 * 4, generator=g)
         ref = ref + od[:, :Cout].repeat_interleave(K, 0).double()
@@ -438,7 +461,7 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
     return act, _conv(W.to(cuda), bias.to(cuda)), ref
 
 
-@pytest.mark.parametrize("kind", ["plain", "radd", "gath", "rgath"])
+@pytest.mark.parametrize("kind", ["plain", "radd", "gath", "rgath", "rknn"])
 def test_narrow_layers_on_128_row_tiles(cuda, kind):
     """Tile variants 7 / 8 (128 rows, 32-channel chunks: the level-0 / level-1 narrow layers): channel counts that
     end inside a chunk, all prologue / epilogue options, more tiles than resident workgroups (persistent loop) with
@@ -471,11 +494,12 @@ def test_narrow_layers_on_128_row_tiles(cuda, kind):
 
 
 @pytest.mark.parametrize("B,rpb,Cin,Cout", [(2, 256, 128, 128), (3, 64, 256, 256), (2, 1024, 100, 140), (2, 384, 64, 96)])
-def test_gathered_residual_on_wide_tiles(cuda, B, rpb, Cin, Cout):
+@pytest.mark.parametrize("kind", ["rgath", "rknn"])
+def test_gathered_residual_on_wide_tiles(cuda, B, rpb, Cin, Cout, kind):
     """A gathered residual (the residual conv of a virtual first conv) through the 128- / 64-row wide tiles and
     through a shape without a wave-specialised instantiation (128 x 160: uniform-wave kernel)."""
     for seed in (3, 12, 21):
-        act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, "rgath")
+        act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind)
         Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=Cout)
         torch.cuda.synchronize()
         got = Y[:, :Cout].double().cpu()
