@@ -221,7 +221,8 @@ typedef struct {
   const float *scale;   /* (B,Cin) or NULL(=1)  x' = post(pre(x)*scale + shift) + add + residual */
   const float *shift;   /* (B,Cin) or NULL(=0) */
   const float *add;     /* (B,Cin) rows of leading dimension add_ld, or NULL */
-  pdr_seg_t rseg;       /* row-wise residual over all Cin channels (ptr NULL = none); may be gathered */
+  pdr_seg_t rseg;       /* row-wise residual over all Cin channels (ptr NULL = none); may be gathered (ball or
+                         * kNN form, sharing gidx / gcnt / gs1 / gs2 with the sources; the sources are plain then) */
   int add_ld;
   int pre_relu, post_relu;
   int rows_per_batch;   /* npoint*K: positions per batch element (one GroupNorm instance) */
@@ -275,7 +276,10 @@ int pdr_fused_layer_bf16x3(const pdr_layer_in_t *in, long P, int Cin, const void
 /* pdr_fused_layer whose output (the attention scores, D channels) is consumed in the epilogue:
  * out[q,:] = sum_k softmax_k(mask(scores))[k,:] * act(values[q*K+k,:]*vscale + vshift); the (P x D)
  * score tensor is never written.  K in {8,16,32}; counts (P/K) or NULL = all neighbours valid.
- * = weight_conv's last Conv2d + mask + F.softmax + weighted sum (attention.py:83-96). */
+ * = weight_conv's last Conv2d + mask + F.softmax + weighted sum (attention.py:83-96).
+ * Plain (not gathered) sources without residual or per-query output term; rows_per_batch % 32 == 0.
+ * Carried by the wave-specialised tiles when rows_per_batch is a multiple of the tile rows (every shape of the
+ * shipped configs), by the uniform-wave kernel otherwise. */
 int pdr_fused_layer_pool(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                          const float *bias, int D, const float *values, int ldv, const float *vscale,
                          const float *vshift, int v_relu, const int *counts, int K, float *out,
