@@ -344,6 +344,9 @@ int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m
 int pdr_reverse_update(float *x, const float *eps, int ld_eps, const float *z, const float *tab_a,
                        const float *tab_b, const float *tab_c, const long long *t_dev, long npoints,
                        int mode, pdr_stream_t stream);
+/* measurement aid (no reference counterpart): one thread writes the 100 MHz wall clock to *slot on `stream`;
+ * capturable, so a replayed step can carry its own time stamps (tools/lab/step_markers.py) */
+int pdr_mark_time(unsigned long long *slot, pdr_stream_t stream);
 
 #ifdef __cplusplus
 }

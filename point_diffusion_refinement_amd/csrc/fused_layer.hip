@@ -543,7 +543,7 @@ struct FoldPart {
   double mult;
 };
 
-__global__ __launch_bounds__(1024) void gn_fold_kernel(FoldPart p0, FoldPart p1, int C, int Cn, int G,
+__global__ __launch_bounds__(1024) void gn_fold_wide_kernel(FoldPart p0, FoldPart p1, int C, int Cn, int G,
                                                        double n, float eps,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
@@ -619,6 +619,86 @@ __global__ __launch_bounds__(1024) void gn_fold_kernel(FoldPart p0, FoldPart p1,
     }
     scale[static_cast<long>(b) * C + c] = sc;
     shift[static_cast<long>(b) * C + c] = sh;
+  }
+}
+
+// The fold that runs in the step (cpg = Cn / G <= 32): one 256-thread workgroup per (batch element, window of
+// whole groups covering <= 32 channels).  A launch is B x ceil(Cn / window) small workgroups of four waves with
+// 2.5 KB of LDS and < 40 VGPRs, so that it is admitted beside resident layer workgroups of the other stream
+// instead of waiting for a CU to drain (the 1024-thread / 16 KB + 16 C form above could not co-reside with two
+// persistent 512-thread layer workgroups; rocprofv3: 23.5 us per fold inside the two-stream step vs 7 us alone).
+// Lanes 0-31 / 32-63 of a wave read the same 32 channels (256 contiguous bytes of a tile's partial row) of two
+// different tile slices; 8 slices per workgroup, four loads in flight per thread; double sums, fixed order.
+__global__ __launch_bounds__(256) void gn_fold_kernel(FoldPart p0, FoldPart p1, int C, int Cn, int G, int CW,
+                                                      double n, float eps,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ scale,
+                                                      float* __restrict__ shift) {
+  __shared__ double red[4][32][2];
+  __shared__ double cs[32][2];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CW;
+  if (c0 >= Cn) {   // the trailing workgroup: channels outside the normalised range pass through
+    for (int c = Cn + threadIdx.x; c < C; c += 256) {
+      scale[static_cast<long>(b) * C + c] = 1.0f;
+      shift[static_cast<long>(b) * C + c] = 0.0f;
+    }
+    return;
+  }
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  const bool valid = cl < CW && c < Cn;
+  double s1 = 0.0, s2 = 0.0, mult = 1.0;
+  if (valid) {
+    const bool first = c < p0.C;
+    const FoldPart p = first ? p0 : p1;
+    const int col = first ? c : c - p0.C;
+    mult = p.mult;
+    const long stride = static_cast<long>(p.ldp) * 2;
+    const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + col) * 2;
+    for (int t = sl; t < p.tiles_per_batch; t += 32) {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = t + 8 * u;
+        v[u] = tt < p.tiles_per_batch ? *reinterpret_cast<const float2*>(q + tt * stride) : make_float2(0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s1 += v[u].x;
+        s2 += v[u].y;
+      }
+    }
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if ((threadIdx.x & 63) < 32) {
+    red[wave][cl][0] = s1;
+    red[wave][cl][1] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    cs[cl][0] = (red[0][cl][0] + red[1][cl][0] + red[2][cl][0] + red[3][cl][0]) * mult;
+    cs[cl][1] = (red[0][cl][1] + red[1][cl][1] + red[2][cl][1] + red[3][cl][1]) * mult;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && valid) {
+    const int cpg = Cn / G;
+    const int g0 = (cl / cpg) * cpg;
+    double g1 = 0.0, g2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+      g1 += cs[g0 + j][0];
+      g2 += cs[g0 + j][1];
+    }
+    const double cnt = n * cpg;
+    const double mean = g1 / cnt;
+    double var = g2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    const float sc = rstd * gamma[c];
+    scale[static_cast<long>(b) * C + c] = sc;
+    shift[static_cast<long>(b) * C + c] = __builtin_fmaf(-sc, static_cast<float>(mean), beta[c]);
   }
 }
 
@@ -1063,10 +1143,23 @@ extern "C" int pdr_gn_fold(const float* part0, int ldp0, int tpb0, int C0, doubl
   if (part1 && (C1 <= 0 || tpb1 <= 0 || ldp1 < C1)) return PDR_EINVAL;
   const int C = C0 + (part1 ? C1 : 0);
   if (Cn < 0 || Cn > C || (Cn > 0 && (Cn % G != 0 || !gamma || !beta))) return PDR_EINVAL;
-  if (static_cast<size_t>(C) * 16 > 48 * 1024) return PDR_EUNSUPPORTED;
   FoldPart p0{part0, ldp0, tpb0, C0, mult0};
   FoldPart p1{part1, ldp1, tpb1, part1 ? C1 : 0, mult1};
-  hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(1024), static_cast<size_t>(C) * 16,
+  static const bool small_form = [] {
+    const char* e = getenv("PDR_GN_FOLD_SMALL");
+    return !(e && e[0] == '0');
+  }();
+  const int cpg = Cn > 0 ? Cn / G : 1;
+  if (small_form && cpg <= 32) {
+    // windows of whole groups covering <= 32 channels; one more workgroup row for pass-through channels
+    const int CW = (32 / cpg) * cpg;
+    const int nw = (Cn + CW - 1) / CW + (C > Cn ? 1 : 0);
+    hipLaunchKernelGGL(gn_fold_kernel, dim3(nw, B), dim3(256), 0, pdr::as_stream(stream), p0, p1, C, Cn, G,
+                       CW, n, eps, gamma, beta, scale, shift);
+    return pdr::check_launch();
+  }
+  if (static_cast<size_t>(C) * 16 > 48 * 1024) return PDR_EUNSUPPORTED;
+  hipLaunchKernelGGL(gn_fold_wide_kernel, dim3(B), dim3(1024), static_cast<size_t>(C) * 16,
                      pdr::as_stream(stream), p0, p1, C, Cn, G, n, eps, gamma, beta, scale, shift);
   return pdr::check_launch();
 }

@@ -42,7 +42,17 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
   x[i] = r;
 }
 
+// One thread stores the constant-rate (100 MHz) wall clock: a time stamp INSIDE a captured step, readable after an
+// untraced replay (tools/lab/step_markers.py) -- rocprofv3's timeline of a two-stream graph is distorted by the tracer.
+__global__ void mark_time_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
 }  // namespace
+
+extern "C" int pdr_mark_time(unsigned long long* slot, pdr_stream_t stream) {
+  if (!slot) return PDR_EINVAL;
+  hipLaunchKernelGGL(mark_time_kernel, dim3(1), dim3(1), 0, pdr::as_stream(stream), slot);
+  return pdr::check_launch();
+}
 
 extern "C" int pdr_reverse_update(float* x, const float* eps, int ld_eps, const float* z, const float* tab_a,
                                   const float* tab_b, const float* tab_c, const long long* t_dev, long npoints,

@@ -77,10 +77,29 @@ GATHER_RES_KNN = __import__("os").environ.get("PDR_GATHER_RES_KNN", "1") == "1" 
 # embedding launches save -- so the default stays OFF; the rocprofv3 timeline that suggested the opposite turned
 # out to be distorted by the tracer.
 EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
+# Geometry prepass: one event per level instead of one after the whole chain (see _forward_cached).
+# PDR_LEVEL_EVENTS=0 restores the single wait (A/B).
+LEVEL_EVENTS = __import__("os").environ.get("PDR_LEVEL_EVENTS", "1") == "1"
 
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# Time stamps inside a step (tools/lab/step_markers.py sets MARKS = {"buf": uint64 device tensor, "names": []}):
+# mark(name) launches pdr_mark_time on the CURRENT stream; capturable, so the stamps of an untraced graph replay
+# can be read back afterwards.  None = no launches (the default).
+MARKS = None
+
+
+def mark(name, detail=False):
+    if MARKS is None or (detail and not MARKS.get("detail")):
+        return
+    i = len(MARKS["names"])
+    if i >= MARKS["buf"].numel():
+        return
+    MARKS["names"].append(name)
+    _lib.check(_lib.load().pdr_mark_time(MARKS["buf"].data_ptr() + 8 * i, _stream()), "mark_time")
 
 
 def _ptr(t, offset=0):
@@ -595,9 +614,11 @@ class FusedAttention:
                                  npoint * K, scale=s, shift=t, pre_relu=True))
             S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
         s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
+        mark("  blk:main_scores_ready", True)
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
         # (a callable: the value half runs on another stream; calling it joins that stream into this one)
         V, vs, vt = values() if callable(values) else (values if values is not None else self.values(h, B, npoint, K))
+        mark("  blk:joined", True)
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
         cptr = counts.data_ptr() if counts is not None else None
         vsp, vtp = (vs.data_ptr(), vt.data_ptr()) if vs is not None else (None, None)
@@ -858,12 +879,18 @@ class FusedGroupedBlock:
                                 res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
                                 U=self.static_U, V2=V2)
 
+        mark("  blk:first_conv_stats_done", True)
+
         def chain_a():
+            mark("  blk:aux_begin", True)
             h, _, _, _ = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
-            return self.att.values(h, B, m, K)
+            r = self.att.values(h, B, m, K)
+            mark("  blk:aux_values_done", True)
+            return r
         values = _fork_join(B * m * K, chain_a)
         out = self.att(query_feats_cl.reshape(B * m, -1), None, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K,
                        values=values)
+        mark("  blk:pool_done", True)
         return out.view(B, m, -1)
 
 
@@ -1082,6 +1109,7 @@ class FusedCloudConditionNet:
         net, hp, bank = self.net, self.net.hparams, self.bank
         B, N, _ = pointcloud.shape
         _XYZ4.clear()
+        mark("step:begin")
         xyz = pointcloud[:, :, 0:3].contiguous()
         # scale_factor == 1 (checked at construction): xyz / 1 is xyz, bit for bit -- no division kernel, and the
         # 16-byte padded copy of the coordinates serves as the level-0 feature rows too
@@ -1125,16 +1153,34 @@ class FusedCloudConditionNet:
             return (i % (nlev + 1), blk.radius, blk.nsample)
 
         with torch.cuda.stream(side):
+            mark("side:begin")
             fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
             if AHEAD_LEVEL == 0:
                 xyz4(xyz)
+            mark("side:first_ball_query_done")
             ev_first = torch.cuda.Event()
             ev_first.record(side)
+            # Level by level, each with its own events: SA block i starts as soon as ITS sampling / grouping is
+            # known, the feature-transfer block of level i + 1 as soon as its ball query is.  (One event after the
+            # whole chain made the main stream sit idle from the end of the first feature-transfer block, 0.85 ms
+            # into the step, until the last ball query at 1.07 ms -- tools/lab/step_markers.py, untraced replay.)
+            ev_sa, ev_fm = [], {}
             for i, sa in enumerate(self.sa):
                 sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
                 sels.append(sel)
                 l_xyz.append(gather_rows(l_xyz[i], sel))
                 sa_neigh.append(sa.neighbours(l_xyz[i], l_xyz[i + 1]))
+                if LEVEL_EVENTS:
+                    xyz4(l_xyz[i + 1])          # padded coordinates of the new level: produced before its event
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    ev_sa.append(ev)
+                    lv = i + 1
+                    for blk in ([self.enc_map[lv]] if lv < nlev else []) + [self.dec_map[lv]]:
+                        if fm_key(lv, blk) not in fm_neigh:
+                            fm_neigh[fm_key(lv, blk)] = blk.neighbours(l_uvw[lv], l_xyz[lv])
+                    ev_fm[lv] = torch.cuda.Event()
+                    ev_fm[lv].record(side)
             for i in range(nlev + 1):
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
@@ -1145,6 +1191,7 @@ class FusedCloudConditionNet:
                 # by the main stream right after ev_first, so it stays lazy (main) unless it is needed ahead.
                 for t in l_xyz[1:]:
                     xyz4(t)
+            mark("side:encoder_geometry_done")
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
             tables, ev_tables = {}, None
@@ -1165,12 +1212,14 @@ class FusedCloudConditionNet:
                 ev_tables.record(side)
             for i in range(-1, -(len(self.fp) + 1), -1):
                 knn[i] = _ext.knn_group(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
+            mark("side:knn_done")
             ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
             ev_knn.record(side)
 
         # ---- embeddings (A/B: PDR_EARLY_EMBED=0 issues them here, beside the running geometry stream)
         if not early:
             self._embeddings(ts, label)
+        mark("main:embeddings_done")
 
         # ---- query-independent parts of the deep feature-transfer blocks, ahead of time on a third stream
         ahead = {}
@@ -1200,24 +1249,37 @@ class FusedCloudConditionNet:
 
         # ---- feature path ------------------------------------------------------------------------
         main.wait_event(ev_first)
+        mark("main:after_wait_first_ball_query")
         l_feat = [feat0]
         for i, sa in enumerate(self.sa):
+            if LEVEL_EVENTS and i > 0:
+                main.wait_event(ev_fm[i])
             mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i],
                               V2=v2_first if i == 0 else tables.get(id(self.enc_map[i])))
-            if i == 0:
+            mark("main:enc_map%d_done" % i)
+            if LEVEL_EVENTS:
+                main.wait_event(ev_sa[i])
+                if i == 0 and ev_tables is not None:
+                    main.wait_event(ev_tables)
+                mark("main:after_wait_sa%d_geometry" % i)
+            elif i == 0:
                 main.wait_event(ev_all)
                 if ev_tables is not None:
                     main.wait_event(ev_tables)
+                mark("main:after_wait_encoder_geometry")
             sa_in = torch.cat([mapped, l_feat[i]], dim=2)
             centre = gather_rows(sa_in, sels[i])
             l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i],
                              V2=tables.get(id(sa))))
+            mark("main:sa%d_done" % i)
         main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
             mapped = transfer(self.dec_map[i], i % (nlev + 1), dec_cl, l_feat[i], V2=tables.get(id(self.dec_map[i])))
             fp_in = torch.cat([mapped, l_feat[i]], dim=2)
+            mark("main:dec_map%d_done" % (i % (nlev + 1)))
             l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i],
                                        V2=tables.get(id(self.fp[i])))
+            mark("main:fp%d_done" % (i % (nlev + 1)))
         mapped = transfer(self.dec_map[0], 0, dec_cl, l_feat[0], V2=tables.get(id(self.dec_map[0])))
         assert not ahead
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
@@ -1226,6 +1288,7 @@ class FusedCloudConditionNet:
         s, t = self.head_norm.fold([(part, 0, self.head1.Cout, tpb, 1.0)], B, self.head1.Cout, N)
         out, _, _ = run_layer(Act([(Y, 0, self.head1.Cout, Y.shape[1], 1)], B * N, B, N, scale=s, shift=t,
                                   post_relu=True), self.head2)
+        mark("main:head_done")
         eps = out.view(B, N, out.shape[1])[:, :, :self.head2.Cout]
         # (B, N, Cout) view over the layer's 4-float rows; samplers consume it in place (pdr_reverse_update reads a
         # leading dimension), everybody else gets the dense tensor the module returns

@@ -30,3 +30,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured floating-point parity of this session's HIP-vs-reference comparisons (tests/parity.py) ->
+    gpurun_out/parity.json (merged by comparison name; committed as profiles/r3_parity.json)."""
+    try:
+        from tests import parity
+        parity.dump(os.path.join(ROOT, "gpurun_out", "parity.json"))
+    except Exception as e:                                    # bookkeeping must never fail a run
+        print("parity dump skipped:", e)

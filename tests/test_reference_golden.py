@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests import parity
 from tests.golden import inputs as I
 from tests.golden.det_weights import fill_deterministic
 from tests.golden.tiny_config import tiny_pointnet_config
@@ -37,39 +38,72 @@ def gold(name):
     return np.load(os.path.join(GOLD, name))
 
 
+# (container-only dry run of the `hip` code paths of this file over the CPU oracle: PDR_PARITY_FAKE_HIP=1 -m gpu)
+FAKE_HIP = os.environ.get("PDR_PARITY_FAKE_HIP", "0") == "1"
+RECORD_ONLY = os.environ.get("PDR_PARITY_RECORD_ONLY", "0") == "1"     # measure everything, assert nothing
+
+
 class Backend:
+    """cpu-oracle: product layers over the same oracle ops the goldens were generated with -> float32 round-off
+    (the GEMMs of two torch-CPU builds may differ in summation order).  hip: every comparison goes through
+    tests/parity.py -- elementwise |got - want| <= bound * max(|want|, rms of the cloud) -- with the measured
+    maxima recorded (profiles/r3_parity.json).  Bounds on the GPU:
+      LAYER  1e-4   single modules (a few GEMM / GroupNorm / softmax stages),
+      COORD  1e-4   denoised coordinates (north_star), for every cloud without a flipped discrete decision,
+      EPS    see net_close."""
+    LAYER = COORD = parity.NORTH_STAR_RTOL
+
     def __init__(self, kind):
         self.kind = kind
-        self.device = torch.device("cuda:0") if kind == "hip" else torch.device("cpu")
-        # float32 round-off on CPU (same ops, same order) vs 1e-4-class on the GPU
-        self.rtol, self.atol = (1e-5, 1e-6) if kind == "cpu-oracle" else (2e-4, 2e-5)
+        self.device = torch.device("cuda:0") if kind == "hip" and not FAKE_HIP else torch.device("cpu")
+        self.rtol, self.atol = 1e-5, 1e-6
 
     def ops(self):
-        return oracle_ops() if self.kind == "cpu-oracle" else contextlib.nullcontext()
+        return oracle_ops() if self.kind == "cpu-oracle" or FAKE_HIP else contextlib.nullcontext()
 
     def to(self, *ts):
         r = tuple(t.to(self.device) if torch.is_tensor(t) else t for t in ts)
         return r if len(r) > 1 else r[0]
 
-    def net_close(self, got, want):
-        """Whole-network outputs: on the GPU, round-off differences of 100+ chained GEMM / GroupNorm
-        layers are amplified by ReLU kinks and softmax masks in a few elements; require the bulk at
-        1e-3 and every element at 1e-2 (the reverse step multiplies eps by <= 0.02, so denoised
-        coordinates still agree to 1e-4)."""
-        if self.kind == "cpu-oracle":
-            return self.close(got, want, 10)
-        got = got.detach().cpu().numpy()
-        err = np.abs(got - want) / (np.abs(want) + 1.0)
-        assert err.max() < 1e-2 and np.mean(err < 1e-3) > 0.99, (err.max(), np.mean(err < 1e-3))
+    def _check(self, name, got, want, bound, clouds=None, extra=None):
+        if RECORD_ONLY:
+            parity.record(name, self.kind, got, want, bound, clouds, extra)
+        else:
+            parity.check(name, self.kind, got, want, bound, clouds, extra)
 
-    def close(self, got, want, scale=1.0):
+    def net_close(self, got, want, name, x=None, eps_max=None, eps_bulk=None):
+        """Whole-network eps at a FIXED x_t.  Geometry is identical on both sides (index-exact ops on the same
+        bits), so the difference is pure round-off of ~100 chained GEMM / GroupNorm layers.  Two asserts on the GPU:
+          * the quantity north_star bounds -- the denoised coordinates this eps produces through the reverse step
+            with the LARGEST eps coefficient of the schedule ((1 - alpha_t) / sqrt(1 - abar_t) <= 0.02, t = T - 1)
+            -- within 1e-4 (needs x);
+          * eps itself: every element within EPS_MAX of the cloud's scale, 99.9 % within EPS_BULK."""
+        if self.kind == "cpu-oracle":
+            return self.close(got, want, name, 10)
+        self._check(name + ":eps", got, want, self.EPS_MAX if eps_max is None else eps_max)
+        rec = parity.RECORDS[-1]
+        assert RECORD_ONLY or rec["p999_rel"] <= (self.EPS_BULK if eps_bulk is None else eps_bulk), (name, rec)
+        if x is not None:
+            c_eps, sqrt_alpha = 0.02, float(np.sqrt(1 - 0.02))
+            xn = x.detach().cpu().numpy()
+            step = lambda e: (xn - c_eps * e) / sqrt_alpha
+            self._check(name + ":denoised_coordinates", step(got.detach().cpu().numpy()), step(want), self.COORD)
+
+    # measured on MI355X (profiles/r3_parity.json): eps max 6.3e-6 (full DDPM config) / 5.9e-5 (tiny config),
+    # p99.9 4.7e-6 / 3.6e-5; denoised coordinates max 8e-7; samplers (T = 8 / 5 / 4 calls) max 3.8e-6, no flips
+    EPS_MAX, EPS_BULK = 2e-4, 1e-4
+
+    def close(self, got, want, name=None, scale=1.0, bound=None):
+        if self.kind == "hip":
+            assert name is not None
+            return self._check(name, got, want, self.LAYER if bound is None else bound)
         got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
         np.testing.assert_allclose(got, want, rtol=self.rtol * scale, atol=self.atol * scale)
 
 
 @pytest.fixture(params=["cpu-oracle", pytest.param("hip", marks=pytest.mark.gpu)])
 def be(request):
-    if request.param == "hip" and not torch.cuda.is_available():
+    if request.param == "hip" and not torch.cuda.is_available() and not FAKE_HIP:
         pytest.skip("no GPU")
     b = Backend(request.param)
     util.set_device(b.device)
@@ -90,16 +124,16 @@ def test_grouping_layers(be):
                 q = PU.QueryAndGroup(0.35, 8, use_xyz=True, include_abs_coordinate=True,
                                      include_center_coordinate=True, neighbor_def=nd)
                 o, c = q(xyz, new_xyz, feats, subset=subset, return_counts=True)
-                be.close(o, g["qag_%s_%s" % (nd, subset)])
+                be.close(o, g["qag_%s_%s" % (nd, subset)], "qag_%s_%s" % (nd, subset))
                 if nd == "radius":
                     assert np.array_equal(c.cpu().numpy(), g["qag_counts_%s" % subset])
                     assert (g["qag_counts_False"] == 0).any()          # the fixture does contain empty balls
                 else:
                     assert c == 'all'
-        be.close(PU.QueryAndGroup(0.35, 8)(xyz, new_xyz[:, :16].contiguous(), None), g["qag_plain"])
-        be.close(PU.group_knn(new_xyz, xyz, feats, 4, transpose=True), g["group_knn"])
+        be.close(PU.QueryAndGroup(0.35, 8)(xyz, new_xyz[:, :16].contiguous(), None), g["qag_plain"], "qag_plain")
+        be.close(PU.group_knn(new_xyz, xyz, feats, 4, transpose=True), g["group_knn"], "group_knn")
         be.close(PU.average_feature(be.to(torch.from_numpy(g["qag_radius_False"])),
-                                    be.to(torch.from_numpy(g["qag_counts_False"])), 8), g["avg_feature"])
+                                    be.to(torch.from_numpy(g["qag_counts_False"])), 8), g["avg_feature"], "avg_feature")
 
 
 def test_mlp_attention_and_point_modules(be):
@@ -114,19 +148,19 @@ def test_mlp_attention_and_point_modules(be):
                                                 res_connect=True, include_condition=True, condition_dim=40,
                                                 include_second_condition=True, second_condition_dim=24), 1)
         h = mlp.to(be.device)(grouped, t_emb, c_emb, c2_emb)
-        be.close(h, g["mlp"], 5)
+        be.close(h, g["mlp"], "mlp", 5)
         m2 = fill_deterministic(Mlp_plus_t_emb([32, 32, 32], True, include_t=False, bn_first=True, bias=True,
                                                first_conv=True, first_conv_in_channel=15, res_connect=True), 2)
-        be.close(m2.to(be.device)(grouped), g["mlp_bn_first"], 5)
+        be.close(m2.to(be.device)(grouped), g["mlp_bn_first"], "mlp_bn_first", 5)
         att = fill_deterministic(AttentionModule(6, 15, 6, 15, 48), 3).to(be.device)
         hg = be.to(torch.from_numpy(g["mlp"]))
-        be.close(att(q, grouped, hg, counts), g["attention"], 5)
-        be.close(att(q, grouped, hg, 'all'), g["attention_all"], 5)
+        be.close(att(q, grouped, hg, counts), g["attention"], "attention", 5)
+        be.close(att(q, grouped, hg, 'all'), g["attention_all"], "attention_all", 5)
         fm = fill_deterministic(FeatureMapModule([6, 32, 32], 0.35, 8, include_abs_coordinate=True,
                                                  include_center_coordinate=True, bn_first=False,
                                                  attention_setting=ATT, query_feature_dim=6), 4).to(be.device)
         be.close(fm(xyz, feats, new_xyz, subset=False, record_neighbor_stats=False, features_at_new_xyz=q),
-                 g["feature_map"], 5)
+                 g["feature_map"], "feature_map", 5)
         sa = fill_deterministic(PointnetSAModule([6, 32, 32, 48], npoint=24, radius=0.4, nsample=8, bias=True,
                                                  include_abs_coordinate=True, include_center_coordinate=True,
                                                  t_dim=64, include_t=True, res_connect=True, include_condition=True,
@@ -134,18 +168,18 @@ def test_mlp_attention_and_point_modules(be):
                                                  second_condition_dim=24, attention_setting=ATT), 5).to(be.device)
         sa_xyz, sa_feat = sa(xyz, feats, t_emb, c_emb, c2_emb)
         assert np.array_equal(sa_xyz.cpu().numpy(), g["sa_xyz"])         # FPS picks are exact
-        be.close(sa_feat, g["sa_feat"], 5)
+        be.close(sa_feat, g["sa_feat"], "sa_feat", 5)
         sp = fill_deterministic(PointnetSAModule([6, 32, 32, 48], npoint=24, radius=0.4, nsample=8, bias=True),
                                 6).to(be.device)
-        be.close(sp(xyz, feats, pooling='avg_max')[1], g["sa_pool_feat"], 5)
+        be.close(sp(xyz, feats, pooling='avg_max')[1], g["sa_pool_feat"], "sa_pool_feat", 5)
         sa_feat_g = be.to(torch.from_numpy(g["sa_feat"]))
         fp = fill_deterministic(PointnetKnnFPModule([48, 32, 32], [32 + 6, 32, 32], 4, bias=True, t_dim=64,
                                                     include_t=True, res_connect=True, include_condition=True,
                                                     condition_dim=40, include_second_condition=True,
                                                     second_condition_dim=24, attention_setting=ATT), 7).to(be.device)
-        be.close(fp(xyz, sa_xyz, feats, sa_feat_g, t_emb, c_emb, c2_emb), g["knn_fp"], 5)
+        be.close(fp(xyz, sa_xyz, feats, sa_feat_g, t_emb, c_emb, c2_emb), g["knn_fp"], "knn_fp", 5)
         fp3 = fill_deterministic(PointnetFPModule([48 + 6, 32, 32], bias=True), 8).to(be.device)
-        be.close(fp3(xyz, sa_xyz, feats, sa_feat_g), g["three_nn_fp"], 5)
+        be.close(fp3(xyz, sa_xyz, feats, sa_feat_g), g["three_nn_fp"], "three_nn_fp", 5)
 
 
 def _quiet(fn, *a, **k):
@@ -169,15 +203,16 @@ def test_full_ddpm_config_forward_matches_reference(be):
     if be.kind == "cpu-oracle":
         assert np.array_equal(first.numpy(), g["eps_first"]) and np.array_equal(cached.numpy(), g["eps_cached"])
         return
-    be.net_close(first, g["eps_first"])
-    be.net_close(cached, g["eps_cached"])
+    be.net_close(first, g["eps_first"], "ddpm_full:eps_first", x)
+    be.net_close(cached, g["eps_cached"], "ddpm_full:eps_cached", x * 0.9)
     from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
     fused = FusedCloudConditionNet(net)
     net.reset_cond_features()
     with torch.no_grad():
-        be.net_close(fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"])
+        be.net_close(fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"],
+                     "ddpm_full_fused:eps_first", x)
         be.net_close(fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True),
-                     g["eps_cached"])
+                     g["eps_cached"], "ddpm_full_fused:eps_cached", x * 0.9)
 
 
 def test_network_forward_caching_and_samplers(be):
@@ -185,31 +220,65 @@ def test_network_forward_caching_and_samplers(be):
     x, cond, ts, label = be.to(*I.network_inputs())
     net = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 11).eval().to(be.device)
     with torch.no_grad(), be.ops():
-        be.net_close(net(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"])
+        be.net_close(net(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"],
+                     "tiny:eps_first", x)
         assert net.l_uvw is not None and net.global_feature is not None
-        be.net_close(net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True), g["eps_cached"])
+        be.net_close(net(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True), g["eps_cached"],
+                     "tiny:eps_cached", x * 0.9)
         net.reset_cond_features()
         assert net.l_uvw is None and net.encoder_cond_features is None and net.decoder_cond_features is None
-        be.net_close(net(x * 0.9, cond, ts=ts - 1, label=label), g["eps_uncached"])
+        be.net_close(net(x * 0.9, cond, ts=ts - 1, label=label), g["eps_uncached"], "tiny:eps_uncached", x * 0.9)
         assert net.l_uvw is None                                          # no retention without the flag
 
-        # identical seeds == identical CPU noise stream (x_T, z_{T-1} .. z_1)
-        dh = util.calc_diffusion_hyperparams(8, 1e-4, 0.02)
-        torch.manual_seed(123)
-        out = _quiet(util.sampling, net, tuple(x.shape), dh, label=label, verbose=False, condition=cond)
-        be.close(out, g["sampling_T8"], 50)
-        assert net.l_uvw is None                                          # sampling() resets the cache
-        dh20 = util.calc_diffusion_hyperparams(20, 1e-4, 0.02)
-        steps = util_fastdpmv2.get_STEP_step(5, {"T": 20, "beta_0": 1e-4, "beta_T": 0.02}, 'quadratic')
-        torch.manual_seed(124)
-        out = _quiet(util_fastdpmv2.STEP_sampling, net, tuple(x.shape), dh20, steps, 0.5, label=label,
-                     verbose=False, condition=cond)
-        be.close(out, g["step_sampling"], 50)
-        eta = np.array([1e-4, 0.004, 0.012, 0.03], dtype=np.float64)
-        torch.manual_seed(125)
-        out = _quiet(util_fastdpmv2.VAR_sampling, net, tuple(x.shape), dh20, eta, 0.5, [17.3, 9.8, 4.1, 0.01],
-                     label=label, verbose=False, condition=cond)
-        be.close(out, g["var_sampling"], 50)
+    # identical seeds == identical CPU noise stream (x_T, z_{T-1} .. z_1)
+    dh = util.calc_diffusion_hyperparams(8, 1e-4, 0.02)
+    dh20 = util.calc_diffusion_hyperparams(20, 1e-4, 0.02)
+    steps = util_fastdpmv2.get_STEP_step(5, {"T": 20, "beta_0": 1e-4, "beta_T": 0.02}, 'quadratic')
+    eta = np.array([1e-4, 0.004, 0.012, 0.03], dtype=np.float64)
+    loops = [
+        ("sampling_T8", 123, lambda n, c, l: util.sampling(n, tuple(x.shape), dh, label=l, verbose=False, condition=c)),
+        ("step_sampling", 124, lambda n, c, l: util_fastdpmv2.STEP_sampling(n, tuple(x.shape), dh20, steps, 0.5, label=l,
+                                                                            verbose=False, condition=c)),
+        ("var_sampling", 125, lambda n, c, l: util_fastdpmv2.VAR_sampling(n, tuple(x.shape), dh20, eta, 0.5,
+                                                                          [17.3, 9.8, 4.1, 0.01], label=l,
+                                                                          verbose=False, condition=c)),
+    ]
+    cpu_net = None
+    for name, seed, loop in loops:
+        rec = parity.InputRecorder(net)
+        with torch.no_grad(), be.ops():
+            torch.manual_seed(seed)
+            out = _quiet(loop, net, cond, label)
+        rec.close()
+        assert net.l_uvw is None                                          # the loops reset the cache
+        if be.kind == "cpu-oracle":
+            be.close(out, g[name], name, 50)
+            continue
+        # hip: replay the same loop over the CPU oracle (== the reference golden, checked by the cpu-oracle
+        # parameter of this test), recompute every discrete decision of every network call from both trajectories
+        # and hold every cloud WITHOUT a flipped decision to north_star's 1e-4
+        if cpu_net is None:
+            cpu_net = fill_deterministic(PointNet2CloudCondition(tiny_pointnet_config()), 11).eval()
+        util.set_device(torch.device("cpu"))
+        try:
+            rec_cpu = parity.InputRecorder(cpu_net)
+            with torch.no_grad(), oracle_ops():
+                torch.manual_seed(seed)
+                want = _quiet(loop, cpu_net, cond.cpu(), label.cpu())
+            rec_cpu.close()
+        finally:
+            util.set_device(be.device)
+        np.testing.assert_allclose(want.numpy(), g[name], rtol=5e-4, atol=5e-5)      # the replay IS the golden loop
+        flipped, first = parity.flipped_clouds(tiny_pointnet_config(), rec.xs, rec_cpu.xs, cond)
+        extra = {"network_calls": len(rec.xs), "flipped_clouds": int(flipped.sum()),
+                 "first_flip": [None if f is None else list(f) for f in first]}
+        be._check(name + ":denoised_coordinates", out, g[name], be.COORD, clouds=~flipped, extra=extra)
+        assert flipped.sum() <= FLIP_ALLOWANCE, (name, first)
+        if flipped.any():                                                 # a flipped cloud is still a valid sample
+            be._check(name + ":flipped_clouds", out, g[name], 5e-2, clouds=flipped)
+
+
+FLIP_ALLOWANCE = 1        # clouds (of 2) per loop that may take one different discrete decision; measured: 0
 
 
 def test_refinement_network_and_upsampling(be):
@@ -220,13 +289,19 @@ def test_refinement_network_and_upsampling(be):
     assert cfg["out_dim"] == 15                                           # 3 * (f + 1)
     with torch.no_grad(), be.ops():
         disp = net(x * 0.3, cond, ts=None, label=label)
-    be.net_close(disp, g["refine_displacement"])
+    # The refinement head's raw output is a small difference of large activations (measured on MI355X: max 4.4e-3,
+    # median 3.3e-5 of its RMS); what the harness consumes is x + 0.001 * displacement (completion_eval.py:159-168),
+    # i.e. the refined COORDINATES -- those carry north_star's 1e-4 (measured 4e-7)
+    be.net_close(disp, g["refine_displacement"], "tiny:refine_displacement", eps_max=2e-2, eps_bulk=1e-2)
+    if be.kind == "hip":
+        up_hip, _ = point_upsample(x * 0.3, disp, 4, False, 0.001)
+        be._check("tiny:refined_coordinates", up_hip, g["upsampled"], be.COORD)
     dg = be.to(torch.from_numpy(g["refine_displacement"]))
     up, centre = point_upsample(x * 0.3, dg, 4, False, 0.001)
-    be.close(up, g["upsampled"])
-    be.close(centre, g["upsample_centre"])
+    be.close(up, g["upsampled"], "upsampled")
+    be.close(centre, g["upsample_centre"], "upsample_centre")
     assert up.shape == (2, 128 * 4, 3)
-    be.close(point_upsample(x * 0.3, dg, 5, True, 0.001)[0], g["upsampled_with_centre"])
+    be.close(point_upsample(x * 0.3, dg, 5, True, 0.001)[0], g["upsampled_with_centre"], "upsampled_with_centre")
 
 
 def test_metrics_python_surface(be):
@@ -234,22 +309,22 @@ def test_metrics_python_surface(be):
     gen, gt = be.to(*I.metric_clouds())
     with be.ops():
         cd_p, cd_t, f1 = chamfer_loss_new.Chamfer_F1(f1_threshold=1e-3)(gen, gt)
-        be.close(cd_p, g["cd_p"]), be.close(cd_t, g["cd_t"]), be.close(f1, g["f1"])
+        be.close(cd_p, g["cd_p"], "cd_p"), be.close(cd_t, g["cd_t"], "cd_t"), be.close(f1, g["f1"], "f1")
         cx, cy, _ = chamfer_loss_new.chamfer_distance(gen, gt[:, :200].contiguous())
-        be.close(cx, g["cham_mean_x"]), be.close(cy, g["cham_mean_y"])
+        be.close(cx, g["cham_mean_x"], "cham_mean_x"), be.close(cy, g["cham_mean_y"], "cham_mean_y")
         w = be.to(torch.tensor([0.5, 2.0, 1.0]))
         cx, cy, _ = chamfer_loss_new.chamfer_distance(gen, gt, weights=w, batch_reduction="sum", point_reduction="sum")
-        be.close(cx, g["cham_wsum_x"]), be.close(cy, g["cham_wsum_y"])
+        be.close(cx, g["cham_wsum_x"], "cham_wsum_x"), be.close(cy, g["cham_wsum_y"], "cham_wsum_y")
         if be.kind == "cpu-oracle":
             emd_dist = emd.EMD_distance.forward
             # emd.py asserts CUDA tensors exactly like the reference; exercise the arithmetic below the assert
             cost = emd.emd_cost_fused(gen.contiguous(), gt.contiguous()) / 256
-            be.close(cost, g["emd"], 10)
+            be.close(cost, g["emd"], "emd", 10)
         else:
-            be.close(emd.EMD_distance()(gen, gt), g["emd"], 1)
+            be.close(emd.EMD_distance()(gen, gt), g["emd"], "emd", 1)
             cost, match = emd.earth_mover_distance(gen.transpose(1, 2), gt[:, :128].transpose(1, 2), transpose=True,
                                                    return_match=True)
-            be.close(cost, g["emd_ragged"], 1)
+            be.close(cost, g["emd_ragged"], "emd_ragged", 1)
             np.testing.assert_allclose(match.sum(1).cpu().numpy(), g["emd_match_rowsum"], rtol=1e-3, atol=1e-4)
             np.testing.assert_allclose(match.sum(2).cpu().numpy(), g["emd_match_colsum"], rtol=1e-3, atol=1e-4)
     # ragged clouds + normals (slow path; pytorch3d semantics of the reference :121-128, 152-155, 162-179): padded
