@@ -344,6 +344,31 @@ int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m
 int pdr_reverse_update(float *x, const float *eps, int ld_eps, const float *z, const float *tab_a,
                        const float *tab_b, const float *tab_c, const long long *t_dev, long npoints,
                        int mode, pdr_stream_t stream);
+/* pdr_reverse_update + the step bookkeeping around it in ONE launch (util.py:246-250 plus the loop header
+ * `for t in range(T-1,-1,-1)` / `ts = t * ones(B)` of :232-236; util_fastdpmv2.py:186-204, 340-376):
+ *   noise:  rng_state != NULL: z ~ N(0,1) drawn in the kernel (Philox4x32-10, key = rng_state[0], counter =
+ *           (element quad, rng_state[1])), `z` ignored; else z as in pdr_reverse_update (NULL = 0);
+ *   after the update the last workgroup (device ticket, `ticket` = one zero-initialised int, left zero) sets
+ *   *t_dev -= 1, *ts_out = ts_table ? ts_table[t-1] : float(t-1) (skipped when ts_out == NULL or t-1 < 0) and
+ *   rng_state[1] += 1.  Same arithmetic, operation order and rounding as pdr_reverse_update. */
+int pdr_reverse_step(float *x, const float *eps, int ld_eps, const float *z, const float *tab_a,
+                     const float *tab_b, const float *tab_c, long long *t_dev, const float *ts_table,
+                     float *ts_out, unsigned long long *rng_state, int *ticket, long npoints, int mode,
+                     pdr_stream_t stream);
+/* ---- step embedding chain -------------------------------------------------------
+ * out (B,N; ld ldo) = act(bias + in . W^T), W (N,K) row-major as nn.Linear stores it, act 0 = none, 1 = swish
+ * (x sigmoid(x)).  in = x (B,K; ld ldx) when ts == NULL, else the sinusoidal step embedding of
+ * pointnet2_ssg_sem.py:14-31 computed on the fly: in[b,k] = sin(ts[b] freq[k]) for k < half, cos(ts[b] freq[k-half])
+ * after (K == 2 half; ts element stride ts_stride, 0 = one step value for the whole batch).  Replaces calc_t_emb,
+ * fc_t1 / fc_t2 + swish (pointnet2_with_pcld_condition.py:183-184) and the per-block fc(t_emb) Linear layers
+ * (pointnet2_modules.py:113-120) of one reverse step: three launches.  K % 8 == 0 and 16-byte aligned rows, else
+ * PDR_EUNSUPPORTED. */
+int pdr_embed_linear(const float *x, int ldx, const float *ts, int ts_stride, const float *freq, int half,
+                     const float *W, const float *bias, int B, int K, int N, int act, float *out, int ldo,
+                     pdr_stream_t stream);
+/* out (rows, ldo) = [src (rows, C) | 0]: channel-last rows padded to a 16-byte multiple (the layer kernels stage
+ * rows with 16-byte loads; replaces F.pad's fill + strided copy) */
+int pdr_pad_rows(const float *src, long rows, int C, float *out, int ldo, pdr_stream_t stream);
 /* measurement aid (no reference counterpart): one thread writes the 100 MHz wall clock to *slot on `stream`;
  * capturable, so a replayed step can carry its own time stamps (tools/lab/step_markers.py) */
 int pdr_mark_time(unsigned long long *slot, pdr_stream_t stream);

@@ -57,7 +57,10 @@ SIGNATURES = {
     "pdr_attention_pool": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_reverse_update": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
+    "pdr_reverse_step": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
+    "pdr_pad_rows": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
     "pdr_mark_time": (_I, [_P, _P]),
+    "pdr_embed_linear": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_gather_add": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
 }
 

@@ -237,6 +237,17 @@ __global__ __launch_bounds__(256) void gather_rows_cl_kernel(const float* __rest
   out[e] = src[(static_cast<long>(b) * n + idx[bj]) * C + c];
 }
 
+// rows of C floats -> rows of ldo >= C floats, zero-filled behind column C (F.pad as ONE launch: torch pads with a
+// fill plus a strided copy)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int C, int ldo, long total,
+                                                       float* __restrict__ out) {
+  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long r = e / ldo;
+  const int c = static_cast<int>(e - r * ldo);
+  out[e] = c < C ? src[r * C + c] : 0.0f;
+}
+
 inline unsigned blocks_for(long total) { return static_cast<unsigned>((total + 255) / 256); }
 
 }  // namespace
@@ -326,6 +337,16 @@ extern "C" int pdr_attention_pool(const float* scores, int lds, const float* val
   hipLaunchKernelGGL(attention_pool_kernel, dim3(blocks_for(rows * (D / 4))), dim3(256), 0,
                      pdr::as_stream(stream), scores, lds, values, ldv, vscale, vshift, v_relu, counts, K,
                      D, npoint, rows, out);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_pad_rows(const float* src, long rows, int C, float* out, int ldo, pdr_stream_t stream) {
+  if (rows < 0 || C <= 0 || ldo < C) return PDR_EINVAL;
+  if (rows == 0) return PDR_OK;
+  if (!src || !out) return PDR_EINVAL;
+  const long total = rows * ldo;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream), src, C, ldo,
+                     total, out);
   return pdr::check_launch();
 }
 

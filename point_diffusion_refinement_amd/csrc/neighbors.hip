@@ -12,6 +12,8 @@
 // first few dozen points most iterations are 8 flops + 1 compare.  Strict `<`
 // plus ascending scan order gives "equal distances: lower index first", which is
 // both the reference three_nn cascade and the knn contract in include/pdr_hip.h.
+#include <cstdlib>
+
 #include "pdr_common.h"
 
 namespace {
@@ -104,6 +106,164 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
       }
     }
   }
+}
+
+// ---- K <= 8 over a cloud of 64 .. 1024 points: one WAVE per query ------------------------------------------------
+// The thread-per-query kernel above keeps a sorted top-K per LANE: its `d < worst` guard is a wave-level branch, and
+// with 64 independent queries per wave some lane takes it in most iterations (P[insert] = K / t per lane at point t),
+// so the 30-instruction shift sequence runs ~600 times per 1024 points; a (2048 x 1024, B = 32) call also launches
+// only 256 workgroups = 1 wave per SIMD.  Measured 266 us = 2.0 TF (profiles/r2_roofline.json).
+// Here the searched cloud lives in VGPRs (lane l holds points l, l + 64, ..., as ball_query.hip) and queries are
+// streamed through as wave-uniform scalars; all 64 lanes work on the SAME query, so there is one threshold:
+//   1. every lane evaluates its NCH distances (same ACC3 expression tree -> same bits as the kernel above);
+//   2. T = max over the eight 8-lane groups of the group's minimum distance: at least 8 points have d <= T;
+//   3. points with d <= T (typically ~20 of 1024) are compacted into LDS in index order (ballot + mbcnt);
+//   4. every candidate's rank = number of candidates with a smaller (distance bits, index) key -- one readlane pair
+//      + one 64-bit compare per candidate; ranks < K are the answer in ascending order, equal distances by lower
+//      index, exactly the contract of the sorted-insertion kernel (bit-identical outputs, tested).
+// More than 64 candidates (massive exact ties) take an exact K-round minimum extraction instead.
+template <int NCH, typename IdxT>
+__global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__ queries,
+                                                       const float* __restrict__ cloud, int nq, int nc, int K,
+                                                       int qpw, float* __restrict__ dists, IdxT* __restrict__ idx,
+                                                       float* __restrict__ nn, float* __restrict__ wgt) {
+  __shared__ unsigned long long cand[4][64];
+  __shared__ float outd[4][8];
+  __shared__ int outi[4][8];
+  __shared__ float outr[4][8];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* c = cloud + static_cast<size_t>(b) * nc * 3;
+  const float* q = queries + static_cast<size_t>(b) * nq * 3;
+  float px[NCH], py[NCH], pz[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int k = ch * 64 + lane;
+    const bool ok = k < nc;
+    // out-of-range slots: +inf -> d = +inf, behind every real point
+    px[ch] = ok ? c[k * 3 + 0] : __builtin_inff();
+    py[ch] = ok ? c[k * 3 + 1] : __builtin_inff();
+    pz[ch] = ok ? c[k * 3 + 2] : __builtin_inff();
+  }
+  const int j0 = (blockIdx.x * 4 + wave) * qpw;
+  for (int jj = 0; jj < qpw; ++jj) {
+    const int j = j0 + jj;   // wave-uniform
+    if (j >= nq) break;
+    const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+    float d[NCH];
+    float m = __builtin_inff();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const float dx = qx - px[ch], dy = qy - py[ch], dz = qz - pz[ch];
+      d[ch] = PDR_ACC3(dx, dy, dz);
+      m = fminf(m, d[ch]);
+    }
+    // minimum of each aligned group of 8 lanes (xor 1, xor 2 inside a quad, then the other quad of the half row),
+    // then the maximum over the wave as unsigned bits (distances are >= 0: bit order == value order)
+    unsigned g = __float_as_uint(m);
+    {
+      unsigned o = __builtin_amdgcn_update_dpp(0u, g, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      g = o < g ? o : g;
+      o = __builtin_amdgcn_update_dpp(0u, g, 0x4E, 0xf, 0xf, false);            // quad_perm [2,3,0,1]
+      g = o < g ? o : g;
+      o = __builtin_amdgcn_update_dpp(0u, g, 0x141, 0xf, 0xf, false);           // row_half_mirror
+      g = o < g ? o : g;
+    }
+    const unsigned T = pdr::wave_max_u32(g);
+    // candidates, compacted in index order
+    int base = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const unsigned bits = __float_as_uint(d[ch]);
+      const bool hit = bits <= T;
+      const unsigned long long mask = __ballot(hit);
+      if (mask != 0ull) {
+        const int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+        if (hit && pos < 64) cand[wave][pos] = pdr::u64_from(bits, static_cast<unsigned>(ch * 64 + lane));
+        base += __builtin_popcountll(mask);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (base <= 64) {
+      const unsigned long long key = lane < base ? cand[wave][lane] : ~0ull;
+      const unsigned klo = static_cast<unsigned>(key), khi = static_cast<unsigned>(key >> 32);
+      int rank = 0;
+      for (int r = 0; r < base; ++r) {
+        const unsigned long long kr =
+            pdr::u64_from(__builtin_amdgcn_readlane(khi, r), __builtin_amdgcn_readlane(klo, r));
+        rank += kr < key ? 1 : 0;
+      }
+      if (lane < base && rank < K) {
+        outd[wave][rank] = __uint_as_float(khi);
+        outi[wave][rank] = static_cast<int>(klo);
+      }
+    } else {
+      // exact fallback: K rounds of wave-wide minimum extraction over (distance bits, index) keys
+      unsigned long long last = 0ull;
+      for (int r = 0; r < K; ++r) {
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          const unsigned long long key = pdr::u64_from(__float_as_uint(d[ch]), static_cast<unsigned>(ch * 64 + lane));
+          if ((r == 0 || key > last) && key < best) best = key;
+        }
+        best = ~pdr::wave_max_u64(~best);
+        if (lane == 0) {
+          outd[wave][r] = __uint_as_float(static_cast<unsigned>(best >> 32));
+          outi[wave][r] = static_cast<int>(static_cast<unsigned>(best));
+        }
+        last = best;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < K) {
+      const float dk = outd[wave][lane];
+      const int ik = outi[wave][lane];
+      const size_t o = (static_cast<size_t>(b) * nq + j) * K + lane;
+      dists[o] = dk;
+      idx[o] = static_cast<IdxT>(ik);
+      if (nn) {
+        nn[o * 3 + 0] = c[ik * 3 + 0];
+        nn[o * 3 + 1] = c[ik * 3 + 1];
+        nn[o * 3 + 2] = c[ik * 3 + 2];
+      }
+      if (wgt) {
+        // group_knn's weights (pointnet2_utils.py:500-503), normalisation summed in ascending-k order as above
+        const float rk = 1.0f / (dk + 1e-8f);
+        outr[wave][lane] = rk;
+        __builtin_amdgcn_wave_barrier();
+        float norm = 0.0f;
+        for (int t = 0; t < K; ++t) norm += outr[wave][t];
+        wgt[o] = rk / norm;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// returns true when the wave-per-query kernel took the call
+template <typename IdxT>
+bool launch_knn_wave(const float* x, const float* y, int B, int n1, int n2, int K, float* dists, IdxT* idx, float* nn,
+                     float* wgt, hipStream_t s) {
+  static const bool on = [] {
+    const char* e = getenv("PDR_KNN_WAVE");
+    return !(e && e[0] == '0');
+  }();
+  if (!on || K > 8 || n2 < 64 || n2 > 1024) return false;
+  int qpw = 16;
+  while (qpw > 1 && static_cast<long long>(B) * ((n1 + 4 * qpw - 1) / (4 * qpw)) < 1024) qpw >>= 1;
+  const dim3 grid((n1 + 4 * qpw - 1) / (4 * qpw), B);
+#define PDR_KW(NCH)                                                                                          \
+  hipLaunchKernelGGL((knn_wave_kernel<NCH, IdxT>), grid, dim3(256), 0, s, x, y, n1, n2, K, qpw, dists, idx, nn, wgt)
+  if (n2 <= 64) PDR_KW(1);
+  else if (n2 <= 128) PDR_KW(2);
+  else if (n2 <= 256) PDR_KW(4);
+  else if (n2 <= 512) PDR_KW(8);
+  else PDR_KW(16);
+#undef PDR_KW
+  return true;
 }
 
 // ---- K = 1 (Chamfer) ------------------------------------------------------------------------
@@ -264,6 +424,7 @@ extern "C" int pdr_knn_points(const float* x, const float* y, int B, int n1, int
     return pdr::check_launch();
   }
   if (K == 1) return launch_knn<1>(x, y, B, n1, n2, K, dists, idx, nn, s);
+  if (K <= n2 && launch_knn_wave<int64_t>(x, y, B, n1, n2, K, dists, idx, nn, nullptr, s)) return pdr::check_launch();
   if (K <= 4) return launch_knn<4>(x, y, B, n1, n2, K, dists, idx, nn, s);
   if (K <= 8) return launch_knn<8>(x, y, B, n1, n2, K, dists, idx, nn, s);
   if (K <= 16) return launch_knn<16>(x, y, B, n1, n2, K, dists, idx, nn, s);
@@ -295,6 +456,7 @@ extern "C" int pdr_knn_group(const float* x, const float* y, int B, int n1, int 
   if (B == 0 || n1 == 0) return PDR_OK;
   if (!x || !y || !dists || !idx || !weights) return PDR_EINVAL;
   hipStream_t s = pdr::as_stream(stream);
+  if (launch_knn_wave<int>(x, y, B, n1, n2, K, dists, idx, nullptr, weights, s)) return pdr::check_launch();
   const dim3 grid((n1 + 255) / 256, B);
 #define PDR_KG(KK)                                                                                      \
   hipLaunchKernelGGL((nn_search_kernel<KK, kAcc3, int, false>), grid, dim3(256), 0, s, x, y, n1, n2, K,  \

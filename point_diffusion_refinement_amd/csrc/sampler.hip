@@ -42,6 +42,100 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
   x[i] = r;
 }
 
+// ---- the same update with the noise drawn in the kernel and the step bookkeeping folded in ------------------------
+// A captured reverse step used to end with four launches: torch's Philox normal kernel (z, 786 KB written and read
+// back), the update above, `t -= 1`, and at the start of the next step `ts = float(t)` (FastDPM: an index_select
+// into the tau table).  Here ONE launch draws z (Philox4x32-10 keyed by a per-batch seed, counter = (element quad,
+// draw number); Box-Muller on two uniform pairs -> four normals per thread), applies the reference expression in
+// the reference's operation order, and the LAST workgroup to finish (device ticket) decrements the step counter,
+// publishes the next step's network time input and advances the draw number.  z never touches memory.
+// The stream of normals is this kernel's own (as `noise='device'` always was: same distribution, not torch's
+// sequence); seed-parity with the reference is the `noise='cpu'` mode, which passes z explicitly.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = static_cast<unsigned>(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n2 = static_cast<unsigned>(p0 >> 32) ^ c3 ^ k1;
+    c1 = static_cast<unsigned>(p1);
+    c3 = static_cast<unsigned>(p0);
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(unsigned v) {   // (0, 1): 24 bits + half an ulp
+  return static_cast<float>(v >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void reverse_step_kernel(float* __restrict__ x, const float* __restrict__ eps,
+                                                           int ld_eps, const float* __restrict__ z,
+                                                           const float* __restrict__ tab_a,
+                                                           const float* __restrict__ tab_b,
+                                                           const float* __restrict__ tab_c,
+                                                           long long* __restrict__ t_ptr,
+                                                           const float* __restrict__ ts_table,
+                                                           float* __restrict__ ts_out,
+                                                           unsigned long long* __restrict__ rng, int* __restrict__ ticket,
+                                                           long total) {
+  const long quad = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long t = *t_ptr;
+  const float a = tab_a[t], b = tab_b[t], c = tab_c[t];
+  float zz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (quad * 4 < total) {
+    if (rng) {
+      const unsigned long long seed = rng[0], draw = rng[1];
+      unsigned r[4];
+      philox4x32_10(static_cast<unsigned>(quad), static_cast<unsigned>(quad >> 32), static_cast<unsigned>(draw),
+                    static_cast<unsigned>(draw >> 32), static_cast<unsigned>(seed), static_cast<unsigned>(seed >> 32),
+                    r);
+      const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), r1 = sqrtf(-2.0f * logf(u01(r[2])));
+      float s0, c0, s1, c1;
+      sincosf(6.283185307179586f * u01(r[1]), &s0, &c0);
+      sincosf(6.283185307179586f * u01(r[3]), &s1, &c1);
+      zz[0] = r0 * c0, zz[1] = r0 * s0, zz[2] = r1 * c1, zz[3] = r1 * s1;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long i = quad * 4 + e;
+      if (i < total) {
+        const long p = i / 3;
+        const int d = static_cast<int>(i - p * 3);
+        const float ev = eps[p * ld_eps + d];
+        const float zv = rng ? zz[e] : (z ? z[i] : 0.0f);
+        const float xv = x[i];
+        float r;
+        if (MODE == 0) {
+          r = (xv - a * ev) / b;
+          r = r + c * zv;
+        } else {
+          r = xv * a;
+          r = r + (b * ev + c * zv);
+        }
+        x[i] = r;
+      }
+    }
+  }
+  // step bookkeeping by the last workgroup: every workgroup has read *t_ptr / rng before it takes its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int old = atomicAdd(ticket, 1);
+    if (old == static_cast<int>(gridDim.x) - 1) {
+      *ticket = 0;
+      const long long tn = t - 1;
+      *t_ptr = tn;
+      if (ts_out && tn >= 0) *ts_out = ts_table ? ts_table[tn] : static_cast<float>(tn);
+      if (rng) rng[1] += 1ull;
+    }
+  }
+}
+
 // One thread stores the constant-rate (100 MHz) wall clock: a time stamp INSIDE a captured step, readable after an
 // untraced replay (tools/lab/step_markers.py) -- rocprofv3's timeline of a two-stream graph is distorted by the tracer.
 __global__ void mark_time_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
@@ -68,5 +162,25 @@ extern "C" int pdr_reverse_update(float* x, const float* eps, int ld_eps, const 
   else
     hipLaunchKernelGGL(reverse_update_kernel<1>, grid, dim3(256), 0, s, x, eps, ld_eps, z, tab_a, tab_b, tab_c, t_dev,
                        npoints);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_reverse_step(float* x, const float* eps, int ld_eps, const float* z, const float* tab_a,
+                                const float* tab_b, const float* tab_c, long long* t_dev, const float* ts_table,
+                                float* ts_out, unsigned long long* rng_state, int* ticket, long npoints, int mode,
+                                pdr_stream_t stream) {
+  if (!x || !eps || !tab_a || !tab_b || !tab_c || !t_dev || !ticket || npoints < 0 || ld_eps < 3 ||
+      (mode != 0 && mode != 1))
+    return PDR_EINVAL;
+  if (npoints == 0) return PDR_OK;
+  const long total = npoints * 3;
+  const dim3 grid(static_cast<unsigned>(((total + 3) / 4 + 255) / 256));
+  hipStream_t s = pdr::as_stream(stream);
+  if (mode == 0)
+    hipLaunchKernelGGL(reverse_step_kernel<0>, grid, dim3(256), 0, s, x, eps, ld_eps, z, tab_a, tab_b, tab_c, t_dev,
+                       ts_table, ts_out, rng_state, ticket, total);
+  else
+    hipLaunchKernelGGL(reverse_step_kernel<1>, grid, dim3(256), 0, s, x, eps, ld_eps, z, tab_a, tab_b, tab_c, t_dev,
+                       ts_table, ts_out, rng_state, ticket, total);
   return pdr::check_launch();
 }

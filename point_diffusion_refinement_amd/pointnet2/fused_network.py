@@ -80,6 +80,9 @@ EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
 # Geometry prepass: one event per level instead of one after the whole chain (see _forward_cached).
 # PDR_LEVEL_EVENTS=0 restores the single wait (A/B).
 LEVEL_EVENTS = __import__("os").environ.get("PDR_LEVEL_EVENTS", "1") == "1"
+# Step-embedding chain (sin / cos, fc_t1, swish, fc_t2, swish, every block's fc(t_emb)) as three pdr_embed_linear
+# launches instead of ~12 torch / hipBLASLt ones.  PDR_NATIVE_EMBED=0: the torch chain (A/B, cross-check).
+NATIVE_EMBED = __import__("os").environ.get("PDR_NATIVE_EMBED", "1") == "1"
 
 
 def _stream():
@@ -216,7 +219,14 @@ def xyz4(t):
     if hit is None:
         # the entry holds the SOURCE too: while it lives, the allocator cannot hand the source's address to
         # another same-shape tensor, so a key can never alias a different tensor within one forward
-        hit = (t, torch.nn.functional.pad(t, (0, -t.shape[-1] % 4)).contiguous())
+        C = t.shape[-1]
+        if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            padded = torch.empty(t.shape[:-1] + (_pad4(C),), dtype=torch.float32, device=t.device)
+            _lib.check(_lib.load().pdr_pad_rows(t.data_ptr(), t.numel() // C, C, padded.data_ptr(), _pad4(C),
+                                                _stream()), "pad_rows")
+        else:
+            padded = torch.nn.functional.pad(t, (0, -C % 4)).contiguous()
+        hit = (t, padded)
         _XYZ4[key] = hit
     return hit[1]
 
@@ -1093,9 +1103,10 @@ class FusedCloudConditionNet:
         class-embedding GEMM when the label tensor changed (identity + version), both IN PLACE."""
         net, hp, bank = self.net, self.net.hparams, self.bank
         if ts is not None and hp['include_t']:
-            t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
-            t_emb = net.activation(net.fc_t2(t_emb))
-            bank.evaluate_kind("t", t_emb)
+            if not (NATIVE_EMBED and ts.is_cuda and "t" in bank.W and self._embed_linear_chain(ts)):
+                t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
+                t_emb = net.activation(net.fc_t2(t_emb))
+                bank.evaluate_kind("t", t_emb)
         # (the key holds the tensor itself: while it is referenced here its address cannot be recycled)
         key = (label, label._version)
         if self._label_key is None or self._label_key[0] is not label or self._label_key[1] != label._version \
@@ -1104,6 +1115,39 @@ class FusedCloudConditionNet:
             self._label_key = key
         if "c" not in bank.out:
             bank.evaluate_kind("c", net.global_feature, static=True)
+
+    def _embed_linear_chain(self, ts):
+        """calc_t_emb -> fc_t1 -> swish -> fc_t2 -> swish -> every block's fc (pointnet2_with_pcld_condition.py
+        :183-184, pointnet2_modules.py:113-120) through pdr_embed_linear; False when the shapes are outside the
+        kernel's contract (caller runs the torch chain)."""
+        net, bank, lib = self.net, self.bank, _lib.load()
+        t_dim = net.hparams['t_dim']
+        if t_dim % 8 != 0 or ts.dim() != 1:
+            return False
+        if ts.dtype != torch.float32:
+            ts = ts.float()
+        from .models.pointnet2_ssg_sem import _frequencies
+        B, half = ts.shape[0], t_dim // 2
+        freq = _frequencies(half, ts.device)
+        dev = ts.device
+        h1 = torch.empty((B, 4 * t_dim), dtype=torch.float32, device=dev)
+        h2 = torch.empty((B, 4 * t_dim), dtype=torch.float32, device=dev)
+        Wb, bb = bank.W["t"], bank.b["t"]
+        out = torch.empty((B, Wb.shape[0]), dtype=torch.float32, device=dev)
+        w1, w2 = net.fc_t1.weight, net.fc_t2.weight
+        st = _stream()
+        rc = lib.pdr_embed_linear(None, 0, ts.data_ptr(), ts.stride(0), freq.data_ptr(), half, w1.data_ptr(),
+                                  net.fc_t1.bias.data_ptr(), B, t_dim, 4 * t_dim, 1, h1.data_ptr(), h1.shape[1], st)
+        if rc == _lib.PDR_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "embed_linear")
+        _lib.check(lib.pdr_embed_linear(h1.data_ptr(), h1.shape[1], None, 0, None, 0, w2.data_ptr(),
+                                        net.fc_t2.bias.data_ptr(), B, 4 * t_dim, 4 * t_dim, 1, h2.data_ptr(),
+                                        h2.shape[1], st), "embed_linear")
+        _lib.check(lib.pdr_embed_linear(h2.data_ptr(), h2.shape[1], None, 0, None, 0, Wb.data_ptr(), bb.data_ptr(), B,
+                                        4 * t_dim, Wb.shape[0], 0, out.data_ptr(), out.shape[1], st), "embed_linear")
+        bank.out["t"] = out
+        return True
 
     def _forward_cached(self, pointcloud, condition, ts, label):
         net, hp, bank = self.net, self.net.hparams, self.bank

@@ -40,8 +40,6 @@ class GraphedReverseSampler:
         self.sigma = sig.to(self.device)
         self._graph = None
         self._key = None
-        if hasattr(net, "return_strided_eps"):
-            net.return_strided_eps = True              # fused network: hand over its 4-float output rows as a view
 
     # ------------------------------------------------------------------ one step
     NOISE_AT_LAST_STEP = False     # util.sampling draws no noise at t = 0
@@ -62,29 +60,57 @@ class GraphedReverseSampler:
         c_eps, sqrt_a, sigma = (tab.index_select(0, t) for tab in self._tables())
         return (x - c_eps * eps) / sqrt_a + sigma * z
 
-    def _update_native(self, eps, z):
-        """x <- update(x, eps, z) in place through pdr_reverse_update: step index and constants stay on the device;
+    def _native(self):
+        x = self._x
+        return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 3
+
+    def _step_native(self, eps):
+        """One pdr_reverse_step launch: the update (bit-identical to `_update`), the noise of `noise='device'` drawn
+        inside the kernel, `t -= 1` and the next step's network time input -- all on the device, no other kernel.
         eps may be the strided (.., 4)-row view the fused network's last layer writes."""
         from .. import _lib
         x = self._x
         B, N, _ = x.shape
+        assert eps.dtype == torch.float32 and eps.device == x.device and tuple(eps.shape) == tuple(x.shape), \
+            "eps must be a float32 tensor of x's shape on x's device"
         if not (eps.stride(2) == 1 and eps.stride(0) == N * eps.stride(1)):
             eps = eps.contiguous()
         a, b, c = self._tables()
-        _lib.check(_lib.load().pdr_reverse_update(x.data_ptr(), eps.data_ptr(), eps.stride(1), z.data_ptr(),
-                                                  a.data_ptr(), b.data_ptr(), c.data_ptr(), self._t.data_ptr(), B * N,
-                                                  self.UPDATE_MODE, torch.cuda.current_stream().cuda_stream),
-                   "reverse_update")
+        device_noise = self.noise == 'device'
+        z = None if device_noise else self._z
+        assert z is None or (z.is_contiguous() and z.device == x.device and z.dtype == torch.float32)
+        tab = self._ts_table()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().pdr_reverse_step(
+                x.data_ptr(), eps.data_ptr(), eps.stride(1), None if z is None else z.data_ptr(), a.data_ptr(),
+                b.data_ptr(), c.data_ptr(), self._t.data_ptr(), None if tab is None else tab.data_ptr(),
+                self._ts.data_ptr(), self._rng.data_ptr() if device_noise else None, self._ticket.data_ptr(), B * N,
+                self.UPDATE_MODE, torch.cuda.current_stream(x.device).cuda_stream), "reverse_step")
+
+    def _ts_table(self):
+        """Device table of network time inputs indexed by the step counter, or None = float(t) (DDPM)."""
+        return None
 
     def _step(self):
         t = self._t                                   # (1,) int64 on device, counts down to 0
-        ts = self._timestep(t).expand(self._x.shape[0])
-        eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
+        native = self._native()
+        B = self._x.shape[0]
+        # native: the time input of this step was published by the previous step's pdr_reverse_step (or by begin())
+        ts = (self._ts if native else self._timestep(t)).expand(B)
+        strided = native and hasattr(self.net, "return_strided_eps")
+        saved_flag = getattr(self.net, "return_strided_eps", None)
+        if strided:
+            self.net.return_strided_eps = True         # fused network: hand over its 4-float output rows as a view
+        try:
+            eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
+        finally:
+            if strided:
+                self.net.return_strided_eps = saved_flag
+        if native:
+            self._step_native(eps)
+            return
         z = torch.randn_like(self._x) if self.noise == 'device' else self._z
-        if self._x.is_cuda and self._x.dtype == torch.float32 and self._x.shape[2] == 3:
-            self._update_native(eps, z)
-        else:
-            self._x.copy_(self._update(self._x, eps, t, z))
+        self._x.copy_(self._update(self._x, eps, t, z))
         self._t.sub_(1)
 
     def _prepare(self, size, condition, label):
@@ -97,6 +123,9 @@ class GraphedReverseSampler:
             self._cond = torch.empty_like(condition, device=self.device)
             self._label = None if label is None else torch.empty_like(label, device=self.device)
             self._t = torch.zeros((1,), dtype=torch.int64, device=self.device)
+            self._ts = torch.zeros((1,), dtype=torch.float32, device=self.device)     # network time input of the step
+            self._rng = torch.zeros((2,), dtype=torch.int64, device=self.device)      # Philox key, draw number
+            self._ticket = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._cond.copy_(condition)
         if label is not None:
             self._label.copy_(label)
@@ -104,15 +133,20 @@ class GraphedReverseSampler:
     def _capture(self):
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
-        saved = (self._x.clone(), self._t.clone())
+        state = (self._x, self._t, self._ts, self._rng)
+        saved = [v.clone() for v in state]
+
+        def restore():
+            for v, w in zip(state, saved):
+                v.copy_(w)
         with torch.cuda.stream(s):
             self._step()                               # warm-up on the side stream (allocator, lazy init)
         torch.cuda.current_stream(self.device).wait_stream(s)
-        self._x.copy_(saved[0]), self._t.copy_(saved[1])
+        restore()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._step()
-        self._x.copy_(saved[0]), self._t.copy_(saved[1])
+        restore()
         self._graph = g
         # the graph has baked in the addresses of the retained condition features
         self._static_cache = self._cache_tensors()
@@ -154,6 +188,12 @@ class GraphedReverseSampler:
         self._x.copy_(x_T)
         t0 = self.T - 1 if start_step is None else int(start_step)
         self._t.fill_(t0)
+        self._ts.copy_(self._timestep(self._t))
+        if self.noise == 'device':
+            # key of this batch's in-kernel normal stream: drawn from the CPU default generator (torch.manual_seed
+            # makes a run reproducible); the draw number restarts at 0
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            self._rng.copy_(torch.tensor([seed, 0], dtype=torch.int64))
         self.remaining = t0 + 1
         self._advance_eager()                          # first step: condition branch runs and is retained
         if self._graph is not None:
@@ -250,6 +290,9 @@ class GraphedFastSampler(GraphedReverseSampler):
 
     def _timestep(self, t):
         return self.f_tau.index_select(0, t)
+
+    def _ts_table(self):
+        return self.f_tau
 
     def _tables(self):
         return self.f_scale, self.f_c, self.f_sigma

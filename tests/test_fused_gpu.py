@@ -73,6 +73,56 @@ def test_fused_layer_matches_torch(cuda, P, Cin, Cout, rpb):
         assert _rel(got[..., 0], s1) < 1e-4 and _rel(got[..., 1], s2) < 1e-4
 
 
+@pytest.mark.parametrize("B,K,N,act", [(32, 128, 512, 1), (5, 512, 4104, 0), (40, 32, 128, 1), (1, 64, 33, 0)])
+def test_embed_linear_matches_torch(cuda, B, K, N, act):
+    """pdr_embed_linear (csrc/embed.hip): Linear (+ swish) over B rows, plain input and the sinusoidal-step prologue,
+    against float64 torch; reference: pointnet2_ssg_sem.py:14-31, pointnet2_with_pcld_condition.py:183-184."""
+    from point_diffusion_refinement_amd.pointnet2.models.pointnet2_ssg_sem import _frequencies, calc_t_emb, swish
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + K + N)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    x = torch.randn(B, K, generator=g).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty((B, N), device=cuda)
+    _lib.check(lib.pdr_embed_linear(x.data_ptr(), K, None, 0, None, 0, W.data_ptr(), bias.data_ptr(), B, K, N, act,
+                                    out.data_ptr(), N, st), "embed_linear")
+    want = torch.nn.functional.linear(x.double(), W.double(), bias.double())
+    want = swish(want) if act else want
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # sinusoidal prologue: step values as large as T - 1 = 999 and fractional FastDPM times; a (1,) tensor expanded
+    # to the batch (stride 0) as the samplers pass it
+    half = K // 2
+    freq = _frequencies(half, cuda)
+    for ts in (torch.linspace(0.0, 999.0, B).to(cuda), torch.tensor([417.25], device=cuda).expand(B)):
+        _lib.check(lib.pdr_embed_linear(None, 0, ts.data_ptr(), ts.stride(0), freq.data_ptr(), half, W.data_ptr(),
+                                        bias.data_ptr(), B, K, N, act, out.data_ptr(), N, st), "embed_linear")
+        emb = calc_t_emb(ts.contiguous(), K)                           # f32 sin / cos of the f32 product, as the reference
+        want = torch.nn.functional.linear(emb.double(), W.double(), bias.double())
+        want = swish(want) if act else want
+        np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=5e-6)
+    assert lib.pdr_embed_linear(x.data_ptr(), K, None, 0, None, 0, W.data_ptr(), bias.data_ptr(), B, K - 4, N, 0,
+                                out.data_ptr(), N, st) in (_lib.PDR_EUNSUPPORTED, _lib.PDR_EINVAL)
+
+
+def test_native_step_embedding_chain_equals_the_torch_chain(cuda, monkeypatch):
+    """FusedCloudConditionNet._embeddings: three pdr_embed_linear launches == calc_t_emb / fc_t1 / fc_t2 / bank GEMM."""
+    net, fused = _pair(small_fused_config(), 21, cuda)
+    ts = torch.tensor([13.0, 977.0], device=cuda)
+    label = torch.tensor([1, 7], device=cuda)
+    net.global_feature = torch.zeros((2, 128), device=cuda)
+    with torch.no_grad():
+        monkeypatch.setattr(FN, "NATIVE_EMBED", False)
+        fused._embeddings(ts, label)
+        want = fused.bank.out["t"].clone()
+        monkeypatch.setattr(FN, "NATIVE_EMBED", True)
+        fused._embeddings(ts, label)
+        got = fused.bank.out["t"]
+    assert got.data_ptr() != want.data_ptr()
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    net.global_feature = None
+
+
 def test_groupnorm_fold_matches_torch_groupnorm(cuda):
     g = torch.Generator().manual_seed(3)
     B, rpb, C = 3, 256, 79                                               # MyGroupNorm(32, 79): 64 normalised + 15 pass-through

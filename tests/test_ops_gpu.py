@@ -153,6 +153,28 @@ def test_knn_exact(cuda, B, n1, n2, K):
     assert np.array_equal(host(nn), gathered)
 
 
+@pytest.mark.parametrize("n2,K", [(64, 8), (100, 8), (256, 8), (700, 5), (1024, 8), (1000, 2)])
+def test_knn_wave_kernel_ties_and_partial_chunks(cuda, n2, K):
+    """The wave-per-query kernel (K <= 8, 64 <= n2 <= 1024) on inputs built to stress its selection: an integer
+    lattice (many exactly equal distances -> ranking by lower index), a cloud of identical points (every point is a
+    candidate: > 64 candidates -> the exact extraction fallback), duplicated points, cloud sizes that leave the
+    last 64-point chunk partial; bit-equal to the oracle and to pdr_knn_group."""
+    rr = rng(900 + n2 + K)
+    lattice = rr.integers(-3, 4, (2, n2, 3)).astype(np.float32)
+    same = np.broadcast_to(np.array([0.25, -0.5, 0.125], np.float32), (2, n2, 3)).copy()
+    dup = rr.uniform(-1, 1, (2, n2, 3)).astype(np.float32)
+    dup[:, n2 // 2:] = dup[:, : n2 - n2 // 2]
+    for y in (lattice, same, dup):
+        x = np.concatenate([y[:, :40], rr.integers(-3, 4, (2, 60, 3)).astype(np.float32)], 1)
+        d, i, _ = _ext.knn_points(dev(x, cuda), dev(y, cuda), K)
+        od, oi = O.knn(x, y, K)
+        assert np.array_equal(host(i), oi) and np.array_equal(host(d), od)
+        dg, ig, wg = _ext.knn_group(dev(x, cuda), dev(y, cuda), K)
+        assert np.array_equal(host(ig), oi.astype(np.int32)) and np.array_equal(host(dg), od)
+        recip = 1.0 / (od.astype(np.float64) + 1e-8)
+        np.testing.assert_allclose(host(wg), recip / recip.sum(-1, keepdims=True), rtol=2e-6)
+
+
 @pytest.mark.parametrize("B,n1,n2,K", [(2, 300, 257, 1), (2, 128, 64, 8), (1, 10, 6, 8), (3, 2048, 2048, 1)])
 def test_knn_grad_vs_oracle(cuda, B, n1, n2, K):
     """pdr_knn_points_grad through the C ABI == oracle (atomics: 1e-5 relative to the gradient scale)."""
@@ -372,3 +394,62 @@ def test_reverse_update_is_bit_identical_to_the_torch_expression(cuda, mode):
                                                   a.data_ptr(), b.data_ptr(), c.data_ptr(), t.data_ptr(), B * N, mode,
                                                   torch.cuda.current_stream().cuda_stream), "reverse_update")
         assert torch.equal(got, want), (mode, step, float((got - want).abs().max()))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reverse_step_update_bookkeeping_and_noise(cuda, mode):
+    """pdr_reverse_step: with an explicit z the update is bit-identical to the torch expression AND the launch
+    decrements the device step counter and publishes the next network time input (float(t-1) or tau[t-1]); with
+    in-kernel noise the normals are N(0,1) (moments, no correlation between neighbours / between draws), reproducible
+    from (key, draw number), different for another key or draw, and the draw number advances by one per launch."""
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(50 + mode)
+    B, N, T = 3, 1001, 50                                                  # 9009 elements: a partial last quad
+    x = torch.randn(B, N, 3, generator=g).to(cuda)
+    eps4 = torch.randn(B, N, 4, generator=g).to(cuda)
+    eps = eps4[:, :, :3]
+    z = torch.randn(B, N, 3, generator=g).to(cuda)
+    a, b, c = (torch.rand(T, generator=g).to(cuda) + 0.5 for _ in range(3))
+    tau = (torch.arange(T, dtype=torch.float32) * 1.75 + 0.125).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    ticket = torch.zeros(1, dtype=torch.int32, device=cuda)
+    for step, table in ((T - 1, None), (7, tau), (0, None)):
+        t = torch.tensor([step], dtype=torch.int64, device=cuda)
+        ts = torch.full((1,), -5.0, device=cuda)
+        A, Bc, C = a[step], b[step], c[step]
+        want = (x - A * eps) / Bc + C * z if mode == 0 else (x * A) + (Bc * eps + C * z)
+        got = x.clone()
+        _lib.check(lib.pdr_reverse_step(got.data_ptr(), eps.data_ptr(), eps.stride(1), z.data_ptr(), a.data_ptr(),
+                                        b.data_ptr(), c.data_ptr(), t.data_ptr(), None if table is None else table.data_ptr(),
+                                        ts.data_ptr(), None, ticket.data_ptr(), B * N, mode, st), "reverse_step")
+        assert torch.equal(got, want), (mode, step, float((got - want).abs().max()))
+        assert int(t) == step - 1 and int(ticket) == 0
+        expect_ts = -5.0 if step == 0 else (float(tau[step - 1]) if table is not None else float(step - 1))
+        assert float(ts) == expect_ts
+    # in-kernel noise: isolate z through x = 0, eps = 0, coefficients (a, b, c) = (1, 1, 1)
+    Bn, Nn = 32, 2048
+    one = torch.ones(4, device=cuda)
+    zero_eps = torch.zeros(Bn, Nn, 3, device=cuda)
+
+    def draw(key, number):
+        xs = torch.zeros(Bn, Nn, 3, device=cuda)
+        t = torch.tensor([3], dtype=torch.int64, device=cuda)
+        rng = torch.tensor([key, number], dtype=torch.int64, device=cuda)
+        _lib.check(lib.pdr_reverse_step(xs.data_ptr(), zero_eps.data_ptr(), 3, None, one.data_ptr(), one.data_ptr(),
+                                        one.data_ptr(), t.data_ptr(), None, None, rng.data_ptr(), ticket.data_ptr(),
+                                        Bn * Nn, mode, st), "reverse_step")
+        assert rng.tolist() == [key, number + 1] and int(t) == 2
+        return xs.flatten().double().cpu()
+    z0, z0b, z1, zk = draw(1234567, 0), draw(1234567, 0), draw(1234567, 1), draw(-99, 0)
+    assert torch.equal(z0, z0b) and not torch.equal(z0, z1) and not torch.equal(z0, zk)
+    n = z0.numel()                                                         # 196,608 samples
+    for s in (z0, z1, zk):
+        assert abs(float(s.mean())) < 4 / n ** 0.5 and abs(float(s.var()) - 1) < 4 * (2 / n) ** 0.5
+        assert abs(float((s ** 3).mean())) < 4 * (15 / n) ** 0.5 and abs(float((s ** 4).mean()) - 3) < 4 * (96 / n) ** 0.5
+        assert abs(float((s[1:] * s[:-1]).mean())) < 4 / n ** 0.5         # neighbours (same Philox block / adjacent blocks)
+        assert float(s.abs().max()) < 6.5 and float((s.abs() > 3).double().mean()) > 0.0015
+    assert abs(float((z0 * z1).mean())) < 4 / n ** 0.5 and abs(float((z0 * zk).mean())) < 4 / n ** 0.5
+    # against the normal CDF at a few quantiles
+    for qv, p in ((-1.0, 0.158655), (0.0, 0.5), (0.5, 0.691462), (2.0, 0.977250)):
+        assert abs(float((z0 < qv).double().mean()) - p) < 4 * (p * (1 - p) / n) ** 0.5
