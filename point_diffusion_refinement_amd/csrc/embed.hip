@@ -42,28 +42,37 @@ __global__ __launch_bounds__(256) void embed_linear_kernel(const float* __restri
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  // k blocks of 8: wave w takes blocks w, w + 4, ...
-  for (int kb = wave; kb * 8 < K; kb += 4) {
-    const int k = kb * 8 + 4 * hi;
-    float a[4];
-    if (SINCOS) {
+  // k blocks of 8: wave w takes blocks w, w + 4, ...; four blocks per trip with all eight 16-byte loads issued
+  // before the first MFMA (a trip per block was a chain of dependent ~2 us global loads: 16 trips for K = 512)
+  for (int kb0 = wave; kb0 * 8 < K; kb0 += 16) {
+    float a[4][4];
+    float4 w4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = (kb0 + 4 * u) * 8 + 4 * hi;
+      const bool kok = (kb0 + 4 * u) * 8 < K;          // uniform
+      if (SINCOS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = kok ? k + e : 0;
+          // (torch evaluates ts * freq in f32, then sin / cos of the f32 product)
+          const float arg = tsb * freq[kk < half ? kk : kk - half];
+          a[u][e] = kok ? (kk < half ? sinf(arg) : cosf(arg)) : 0.0f;
+        }
+      } else {
+        const float4 v = kok ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        a[u][0] = v.x, a[u][1] = v.y, a[u][2] = v.z, a[u][3] = v.w;
+      }
+      w4[u] = kok ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int kk = k + e;
-        // (torch evaluates ts * freq in f32, then sin / cos of the f32 product)
-        const float arg = tsb * freq[kk < half ? kk : kk - half];
-        a[e] = kk < half ? sinf(arg) : cosf(arg);
+        const float av = bok ? a[u][e] : 0.0f, wv = nok ? w[e] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
       }
-    } else {
-      const float4 v = *reinterpret_cast<const float4*>(xr + k);
-      a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
-    }
-    const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
-    const float w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float av = bok ? a[e] : 0.0f, wv = nok ? w[e] : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
     }
   }
   // C / D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "pdr_common.h"
+#include "gn_tail_fold.h"
 
 #include <type_traits>
 
@@ -99,7 +100,7 @@ template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool 
 __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int n_row_tiles, int tile_order, pdr::PoolArgs pool) {
+    float* __restrict__ partial, int relu_col0, int n_row_tiles, pdr_fold_t fold, pdr::PoolArgs pool) {
   // SPLIT: `Wt` points at the packed bf16 hi / lo weight image (pdr_pack_weights_bf16x3: per column block and
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
@@ -126,27 +127,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
   // chunks per tile, tiles of this workgroup
   int nch = 0;
   for (int s = 0; s < in.n_seg; ++s) nch += (in.seg[s].C + KC - 1) / KC;
-  // Tile order.  The cursor walks VIRTUAL tile numbers s = blockIdx.x + k gridDim.x; `phys` maps them to row tiles.
-  //   plain:     phys(s) = s -- at any moment the resident workgroups work on consecutive tiles of ONE cloud
-  //   XCD-local: workgroup ids are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2, so XCD x
-  //              owns the clouds x, x + 8, ... and its gridDim.x / 8 workgroups stride over that cloud's tiles:
-  //              a cloud's gathered source table (n_src x C <= 1.5 MB) is fetched into ONE L2 instead of eight
   const int nwg = static_cast<int>(gridDim.x);
-  const int nB = n_row_tiles / tpb;
-  const bool xcd_order = tile_order != 0 && (nwg & 7) == 0 && nB >= 8;   // uniform
-  const int xcd = static_cast<int>(blockIdx.x) & 7, wx = static_cast<int>(blockIdx.x) >> 3, nwx = nwg >> 3;
-  const int xtiles = ((nB - xcd + 7) >> 3) * tpb;                        // row tiles owned by this XCD
-  auto phys = [&](int s) __attribute__((always_inline)) -> int {
-    if (!xcd_order) return s;
-    const int L = wx + (s / nwg) * nwx;
-    const int j = L / tpb;
-    return (xcd + 8 * j) * tpb + (L - j * tpb);
-  };
-  auto tile_valid = [&](int s) __attribute__((always_inline)) -> bool {
-    return xcd_order ? wx + (s / nwg) * nwx < xtiles : s < n_row_tiles;
-  };
-  const int my_tiles = xcd_order ? (xtiles > wx ? (xtiles - wx + nwx - 1) / nwx : 0)
-                                 : (n_row_tiles - static_cast<int>(blockIdx.x) + nwg - 1) / nwg;
+  const int my_tiles = (n_row_tiles - static_cast<int>(blockIdx.x) + nwg - 1) / nwg;
   const int G = my_tiles * nch;
   const bool has_partial = partial != nullptr;
   if (tid == 0) epi_ticket = 0;       // ordered before its first use by the barrier B(0)
@@ -176,6 +158,24 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     c.tile = really ? n.tile : c.tile;
   };
   auto last_of_tile = [&](const Cur& c) { return c.sg == in.n_seg - 1 && c.ks + KC >= in.seg[c.sg].C; };
+
+  // GroupNorm fold of this layer's statistics by the workgroup that completes a batch element (gn_tail_fold.h);
+  // reached by all eight waves after their loops, the dead staging buffers serve as scratch
+  auto tail = [&]() __attribute__((always_inline)) {
+    if constexpr (!POOL) {
+      if (fold.ticket != nullptr) {   // uniform
+        const int bid = static_cast<int>(blockIdx.x);
+        auto units = [&](int b) -> int {   // this workgroup's row tiles bid + k nwg, k < my_tiles, inside batch element b
+          const int lo = b * tpb, hi = lo + tpb;
+          const int k0 = lo > bid ? (lo - bid + nwg - 1) / nwg : 0;
+          const int k1 = hi > bid ? (hi - bid + nwg - 1) / nwg : 0;
+          return max(0, min(k1, my_tiles) - min(k0, my_tiles));
+        };
+        pdr::tail_fold<512>(fold, partial, Cout, tpb, n_row_tiles / tpb, tpb * static_cast<int>(gridDim.y), units,
+                            reinterpret_cast<double*>(&sm));
+      }
+    }
+  };
 
   if (wave >= 4) {
     // =================================== PRODUCERS ===================================
@@ -254,8 +254,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
     // fetch: chunk at cursor c -> registers (address arithmetic + loads only)
     auto fetch = [&](const Cur& c) __attribute__((always_inline)) {
-      const int ptile = phys(c.tile);
-      const int b = ptile / tpb, tb = ptile - b * tpb;
+      const int b = c.tile / tpb, tb = c.tile - b * tpb;
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
       const pdr_seg_t seg = in.seg[c.sg];
@@ -297,9 +296,8 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
           g_tile = c.tile;
         }
         const int nt = c.tile + static_cast<int>(gridDim.x);
-        if (GATH == 1 && last_of_tile(c) && tile_valid(nt)) {   // uniform: prefetch the next tile's indices
-          const int pnt = phys(nt);
-          const int nb = pnt / tpb, ntb = pnt - nb * tpb;
+        if (GATH == 1 && last_of_tile(c) && nt < n_row_tiles) { // uniform: prefetch the next tile's indices
+          const int nb = nt / tpb, ntb = nt - nb * tpb;
           const long nrow0 = static_cast<long>(nb) * rpb + static_cast<long>(ntb) * TM;
           const int nnv = min(TM, rpb - ntb * TM);
           if constexpr (GATH == 1) load_idx(nrow0, nnv, n_idx, n_cnt);
@@ -558,6 +556,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       PDR_T(1, 4 * g + 2);
       __syncthreads();                                 // B(g): stage g full, stage g+1 free
     }
+    tail();
     return;
   }
 
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     PDR_T(0, 4 * g + 2);
     if (last_of_tile(cur)) {
       // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)
-      const int tile = phys(cur.tile);
+      const int tile = cur.tile;
       const int b = tile / tpb, tb = tile - b * tpb;
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
@@ -893,9 +892,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
                 s1 += red[w][c][0];
                 s2 += red[w][c][1];
               }
-              float* o = partial + (static_cast<long>(tile) * Cout + n0 + c) * 2;
-              o[0] = s1;
-              o[1] = s2;
+              pdr::store_partial(partial + (static_cast<long>(tile) * Cout + n0 + c) * 2, s1, s2);
             }
           }
         }
@@ -904,6 +901,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     PDR_T(0, 4 * g + 3);
     advance(cur);
   }
+  tail();
 }
 
 }  // namespace
@@ -957,36 +955,25 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
 // block); instantiated for the 128-column tile variants 4 and 5 only.
 bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
                            int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
-                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split, const PoolArgs* pool) {
+                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split, const PoolArgs* pool,
+                           const pdr_fold_t* fold) {
   if (!fused_layer_ws_supported(id, radd, gath, in, Cin)) return false;
   if (split && id != 4 && id != 5) return false;
   if (pool && (radd || gath || split || in.oadd)) return false;   // pooled epilogue: plain sources, exact arithmetic
   const PoolArgs pa = pool ? *pool : PoolArgs();
+  pdr_fold_t fd = pdr_fold_t();
+  if (fold && partial && !pool) fd = *fold;
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
-  // (PDR_WS_WGS, default 512 = 2 per CU: fewer leaves CUs with a single layer workgroup, i.e. room for the small
-  // kernels of the other stream -- A/B knob)
-  static const long wgs = [] {
-    const char* e = getenv("PDR_WS_WGS");
-    const long v = e ? atol(e) : 512;
-    return v >= 64 && v <= 16384 ? v : 512;
-  }();
-  // PDR_WS_XCD_ORDER: 0 = plain tile order, 1 = XCD-local cloud-major order for the gathered kernels, 2 = for all
-  static const int xcd_knob = [] {
-    const char* e = getenv("PDR_WS_XCD_ORDER");
-    return e ? atoi(e) : 0;
-  }();
-  const int tile_order = (xcd_knob >= 2 || (xcd_knob == 1 && gath)) ? 1 : 0;
-  long cap = (wgs + ncol - 1) / ncol;
-  if (tile_order) cap = cap / 8 * 8;
+  const long cap = (512 + ncol - 1) / ncol;
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, fd, pa)
 #define PDR_WS_POOL(RT, CT, WR, WC, KC)                                                                       \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, fd, pa)
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   const bool knn_res = in.rseg.gV && in.rseg.g_r1;

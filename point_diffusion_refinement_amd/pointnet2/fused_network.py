@@ -80,9 +80,18 @@ EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
 # Geometry prepass: one event per level instead of one after the whole chain (see _forward_cached).
 # PDR_LEVEL_EVENTS=0 restores the single wait (A/B).
 LEVEL_EVENTS = __import__("os").environ.get("PDR_LEVEL_EVENTS", "1") == "1"
+# Start of a step: the geometry stream begins with the FPS chain (the longest dependency chain of the step: with one
+# event per level it decides when SA block 0 can start); the first feature-transfer block's ball query runs on the
+# MAIN stream and the step embeddings beside it on the auxiliary stream.  PDR_FIRST_BALL_MAIN=0: ball query first on the
+# geometry stream, embeddings on the main stream (A/B).
+FIRST_BALL_MAIN = __import__("os").environ.get("PDR_FIRST_BALL_MAIN", "1") == "1"
 # Step-embedding chain (sin / cos, fc_t1, swish, fc_t2, swish, every block's fc(t_emb)) as three pdr_embed_linear
 # launches instead of ~12 torch / hipBLASLt ones.  PDR_NATIVE_EMBED=0: the torch chain (A/B, cross-check).
 NATIVE_EMBED = __import__("os").environ.get("PDR_NATIVE_EMBED", "1") == "1"
+# GroupNorm folds carried by the launch that produces the statistics (pdr_fused_layer_fold / pdr_gather_add_fold,
+# csrc/gn_tail_fold.h) instead of a pdr_gn_fold launch of their own, when the workgroup that completes a batch element
+# has at most PDR_FOLD_TAIL_KB KiB of partial moments to read (0 = always a separate launch).
+FOLD_TAIL_KB = int(__import__("os").environ.get("PDR_FOLD_TAIL_KB", "0"))
 
 
 def _stream():
@@ -356,10 +365,50 @@ def _ldy(Cout):
     return _pad4(Cout) if (Cout <= 64 or Cout % 32 == 0) else (Cout + 31) // 32 * 32
 
 
-def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
+class FoldReq:
+    """GroupNorm fold requested together with the launch that produces its statistics: channels = columns
+    [col0, col0 + C0) of that launch's output (+ the first columns of `second` = (partial, col0, C, tpb, mult))."""
+
+    def __init__(self, norm, C0, n, col0=0, mult0=1.0, second=None):
+        self.norm, self.C0, self.n, self.col0, self.mult0, self.second = norm, C0, n, col0, mult0, second
+
+    @property
+    def C(self):
+        return self.C0 + (self.second[2] if self.second else 0)
+
+    def in_launch(self, B, tpb):
+        """Carry the fold in the producing launch?  (the workgroup completing a batch element reads tpb x C moments)"""
+        tiles = max(tpb, self.second[3] if self.second else 0)
+        return FOLD_TAIL_KB > 0 and B <= 64 and tiles * self.C * 8 <= FOLD_TAIL_KB * 1024
+
+    def struct(self, B, dev):
+        norm, C = self.norm, self.C
+        scale = torch.empty((B, C), dtype=torch.float32, device=dev)
+        shift = torch.empty((B, C), dtype=torch.float32, device=dev)
+        f = _lib.Fold()
+        f.ticket = norm.tickets(B).data_ptr()
+        f.gamma, f.beta = norm.gamma.data_ptr(), norm.beta.data_ptr()
+        f.scale, f.shift = scale.data_ptr(), shift.data_ptr()
+        f.mult0, f.mult1, f.n = float(self.mult0), 1.0, float(self.n)
+        f.col0, f.C0 = self.col0, self.C0
+        if self.second:
+            pb, cb, nb, tb, mb = self.second
+            f.part1, f.ldp1, f.tpb1, f.C1, f.mult1 = _ptr(pb, 2 * cb), pb.shape[1], tb, nb, float(mb)
+        f.Cn, f.G, f.eps = norm.Cn, norm.G, float(norm.eps)
+        return f, scale, shift
+
+    def launch(self, partial, tpb, B):
+        """The fold as a launch of its own (pdr_gn_fold)."""
+        parts = [(partial, self.col0, self.C0, tpb, self.mult0)] + ([self.second] if self.second else [])
+        return self.norm.fold(parts, B, self.C, self.n)
+
+
+def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fold=None):
     """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch).
     extra_rows: zero rows appended to Y (the zero row of a gathered table); out = (tensor, col0): write into
-    columns [col0, col0 + ldy') of an existing (P, ld) tensor instead of allocating."""
+    columns [col0, col0 + ldy') of an existing (P, ld) tensor instead of allocating.
+    fold: a FoldReq -- returns (Y, partial, tiles_per_batch, (scale, shift)) with the GroupNorm fold of this layer's
+    statistics, computed by the layer's own launch where a kernel with a fold tail takes it, else by pdr_gn_fold."""
     lib = _lib.load()
     assert act.C == conv.Cin, (act.C, conv.Cin)
     ldy = _ldy(conv.Cout)
@@ -374,11 +423,22 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
     tm = lib.pdr_fused_layer_tile_rows(act.rpb, conv.Cout)
     tpb = (act.rpb + tm - 1) // tm
     partial = None
+    stats = stats or fold is not None
     if stats:
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
     rc0 = conv.Cout if relu_col0 is None else relu_col0
-    if not _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, rc0):
+    folded = None
+    done = _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, rc0)
+    if not done and fold is not None and fold.in_launch(act.B, tpb):
+        f, scale, shift = fold.struct(act.B, Y.device)
+        rc = lib.pdr_fused_layer_fold(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
+                                      conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, partial.data_ptr(), rc0,
+                                      ctypes.byref(f), _stream())
+        if rc != _lib.PDR_EUNSUPPORTED:
+            _lib.check(rc, "fused_layer_fold")
+            done, folded = True, (scale, shift)
+    if not done:
         rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
                                  conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
                                  partial.data_ptr() if stats else None, rc0, _stream())
@@ -397,7 +457,11 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None):
                                      conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
                                      partial.data_ptr() if stats else None, rc0, _stream())
         _lib.check(rc, "fused_layer")
-    return Y, partial, tpb
+    if fold is None:
+        return Y, partial, tpb
+    if folded is None:
+        folded = fold.launch(partial, tpb, act.B)
+    return Y, partial, tpb, folded
 
 
 def materialize(act):
@@ -415,6 +479,13 @@ class Norm:
         gn = mod.group_norm if isinstance(mod, MyGroupNorm) else mod
         self.G, self.Cn, self.eps = gn.num_groups, gn.num_channels, gn.eps
         self.gamma, self.beta = gn.weight.detach().contiguous(), gn.bias.detach().contiguous()
+
+    def tickets(self, B):
+        """Per-batch-element completion counters of this GroupNorm's in-launch fold (zero between launches)."""
+        t = self.__dict__.setdefault("_tickets", {})
+        if B not in t:
+            t[B] = torch.zeros((B,), dtype=torch.int32, device=self.gamma.device)
+        return t[B]
 
     def fold(self, parts, B, C, n):
         """parts: [(partial, col0, ncols, tiles_per_batch, mult)] (one or two) covering C channels in order.
@@ -537,23 +608,29 @@ class FusedMlp:
         """x: Act over the grouped input.  Returns (h Act [final activation incl. residual], Y1, part1, tpb1)
         where Y1 holds [first conv | res conv | extra convs] columns."""
         relu0 = self.extra_col0 if relu_stats_extra else None
-        Y1, part1, tpb1 = run_layer(x, self.first, stats=True, relu_col0=relu0)
-        return self.after_first(Y1, part1, tpb1, x.P, x.B, x.rpb, bank, x)
+        Y1, part1, tpb1, folded = run_layer(x, self.first, relu_col0=relu0, fold=self.first_fold(x.rpb))
+        return self.after_first(Y1, part1, tpb1, x.P, x.B, x.rpb, bank, x, folded=folded)
 
-    def after_first(self, Y1, part1, tpb1, P, B, rpb, bank, x=None):
-        """Everything behind the first conv, given its output `Y1` (a tensor or a FirstOut)."""
+    def first_fold(self, rpb):
+        """Fold request of the GroupNorm behind the first conv (for whoever launches that conv)."""
+        return FoldReq(self.norms[0], self.C1, rpb)
+
+    def after_first(self, Y1, part1, tpb1, P, B, rpb, bank, x=None, folded=None):
+        """Everything behind the first conv, given its output `Y1` (a tensor or a FirstOut) and, when the first
+        conv's launch carried it, the fold of the first GroupNorm (`folded` = (scale, shift))."""
         first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
         part, tpb = part1, tpb1
         cur = first.attach(Act([first.seg(0, self.C1)], P, B, rpb))
         for i, norm in enumerate(self.norms):
             C = cur.C
-            scale, shift = norm.fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
+            scale, shift = folded if folded is not None else norm.fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
             cur.scale, cur.shift, cur.post_relu = scale, shift, True
             inj = bank.get(self.inject.get(i))
             if inj is not None:
                 cur.add, cur.add_ld = inj[0][:, inj[1]:], inj[2]
             if i < len(self.rest):
-                Y, part, tpb = run_layer(cur, self.rest[i], stats=True)
+                Y, part, tpb, folded = run_layer(cur, self.rest[i],
+                                                 fold=FoldReq(self.norms[i + 1], self.rest[i].Cout, rpb))
                 cur = Act([(Y, 0, self.rest[i].Cout, Y.shape[1], 1)], P, B, rpb)
         if self.has_res:
             if self.res_col0 is not None:
@@ -594,10 +671,9 @@ class FusedAttention:
 
     def values(self, h, B, npoint, K):
         """Value half (independent of the query features): value conv + its GroupNorm fold."""
-        V, pv, tpv = run_layer(h, self.v, stats=self.v_norm is not None)
-        vs = vt = None
-        if self.v_norm is not None:
-            vs, vt = self.v_norm.fold([(pv, 0, self.D, tpv, 1.0)], B, self.D, npoint * K)
+        if self.v_norm is None:
+            return run_layer(h, self.v)[0], None, None
+        V, _, _, (vs, vt) = run_layer(h, self.v, fold=FoldReq(self.v_norm, self.D, npoint * K))
         return V, vs, vt
 
     def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None):
@@ -606,10 +682,12 @@ class FusedAttention:
         lib = _lib.load()
         P = B * npoint * K
         first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
-        q, qpart, qtpb = run_layer(plain(query, B, npoint), self.q, stats=True, relu_col0=0)
+        # GroupNorm over [q.expand(K) | key]: the q half's moments count K times, the key half's come from the first
+        # conv's launch -- both folded at the end of the q conv's launch
         Ct = self.C1 + self.C2
-        s, t = self.n1.fold([(qpart, 0, self.C1, qtpb, float(K)), (part1, key_col0, self.C2, tpb1, 1.0)], B, Ct,
-                            npoint * K)
+        q, qpart, qtpb, (s, t) = run_layer(plain(query, B, npoint), self.q, relu_col0=0,
+                                           fold=FoldReq(self.n1, self.C1, npoint * K, mult0=float(K),
+                                                        second=(part1, key_col0, self.C2, tpb1, 1.0)))
         if SPLIT_QUERY_CONV and (K & (K - 1)) == 0:
             zq = Act([(q, 0, self.C1, q.shape[1], 1)], B * npoint, B, npoint, scale=s, shift=t, pre_relu=True)
             zq.ss_ld = Ct
@@ -618,12 +696,11 @@ class FusedAttention:
                                  shift=t[:, self.C1:], pre_relu=True))
             a.ss_ld = Ct
             a.oadd = (Z, K)
-            S1, p1, tp = run_layer(a, self.w1_k, stats=True, relu_col0=0)
+            S1, _, _, (s, t) = run_layer(a, self.w1_k, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
         else:
             a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B,
                                  npoint * K, scale=s, shift=t, pre_relu=True))
-            S1, p1, tp = run_layer(a, self.w1, stats=True, relu_col0=0)
-        s, t = self.n2.fold([(p1, 0, self.w1.Cout, tp, 1.0)], B, self.w1.Cout, npoint * K)
+            S1, _, _, (s, t) = run_layer(a, self.w1, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
         mark("  blk:main_scores_ready", True)
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
         # (a callable: the value half runs on another stream; calling it joins that stream into this one)
@@ -724,9 +801,10 @@ class SplitFirstConv:
         return V2
 
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
-                 virtual=False, res=None, U=None, V2=None):
-        """-> (Y1, partial, tiles_per_batch).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
-        consumers read as a gathered source (only the GroupNorm moments are computed here)."""
+                 virtual=False, res=None, U=None, V2=None, fold=None):
+        """-> (Y1, partial, tiles_per_batch, folded).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
+        consumers read as a gathered source (only the GroupNorm moments are computed here).  fold: FoldReq of the
+        GroupNorm behind this conv; folded = its (scale, shift) when the launch carried it, else None."""
         lib = _lib.load()
         B, n, Cs = src_feats_cl.shape
         m = query_xyz.shape[1]
@@ -746,16 +824,24 @@ class SplitFirstConv:
         partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
         cptr = counts.data_ptr() if has_v0 else None
 
+        folded = []
+
         def gather_add(y, ldy, ycol0, ycols):
-            _lib.check(lib.pdr_gather_add(
+            fptr = None
+            if fold is not None and fold.in_launch(B, tpb):
+                f, scale, shift = fold.struct(B, U.device)
+                fptr = ctypes.byref(f)
+                folded.append((scale, shift))
+            _lib.check(lib.pdr_gather_add_fold(
                 U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
                 s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
                 s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
-                B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, _stream()), "gather_add")
+                B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, fptr, _stream()),
+                "gather_add")
 
         if not virtual:
             gather_add(Y.data_ptr(), ld, 0, -1)
-            return Y, partial, tpb
+            return Y, partial, tpb, (folded[0] if folded else None)
         # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
         # consumer, which stays a plain read) are written -- one pass
         Yres = None
@@ -783,7 +869,7 @@ class SplitFirstConv:
                          nsrc=n, zrow=B * n, Yres=Yres, res_col0=res[0] if res else 0,
                          res_cols=res[1] if res else 0, s1=s1, s2=s2, r1=self.r1 if s1 is not None else None,
                          r2=self.r2 if s1 is not None else None, materialise=materialise)
-        return first, partial, tpb
+        return first, partial, tpb, (folded[0] if folded else None)
 
 
 def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with_centre):
@@ -857,11 +943,11 @@ class FusedGroupedBlock:
         K = self.nsample
         if USE_SPLIT_FIRST:
             split = self._make_split(src_feats_cl.shape[2])
-            Y1, part1, tpb1 = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
+            Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                     self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                     res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
-                                    U=self.static_U, V2=V2)
-            h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
+                                    U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K))
+            h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank, folded=folded)
         else:
             G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
                                 self.with_centre)
@@ -884,16 +970,16 @@ class FusedGroupedBlock:
         # deep level: first GEMM here, then [MLP + value conv] on the auxiliary stream beside [query / score convs]
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
         split = self._make_split(src_feats_cl.shape[2])
-        Y1, part1, tpb1 = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
+        Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                 self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                 res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
-                                U=self.static_U, V2=V2)
+                                U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K))
 
         mark("  blk:first_conv_stats_done", True)
 
         def chain_a():
             mark("  blk:aux_begin", True)
-            h, _, _, _ = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank)
+            h, _, _, _ = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank, folded=folded)
             r = self.att.values(h, B, m, K)
             mark("  blk:aux_values_done", True)
             return r
@@ -926,17 +1012,18 @@ class FusedKnnFP:
         if USE_SPLIT_FIRST:
             if self.split is None:
                 self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
-            Y1, part1, tpb1 = self.split(
+            Y1, part1, tpb1, folded = self.split(
                 known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0, s1=d2, s2=wgt, V2=V2,
                 virtual=USE_VIRTUAL_FIRST and USE_VIRTUAL_KNN,
-                res=(self.mlp1.res_col0, self.mlp1.Clast) if self.mlp1.res_col0 is not None else None)
+                res=(self.mlp1.res_col0, self.mlp1.Clast) if self.mlp1.res_col0 is not None else None,
+                fold=self.mlp1.first_fold(n * K))
             if _PAR["stream"] is not None and PAR_MIN_ROWS <= B * n * K <= PAR_MAX_ROWS:
                 def chain_a():
-                    hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
+                    hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank, folded=folded)
                     return self.att.values(hh, B, n, K)
                 h, values = None, _fork_join(B * n * K, chain_a)
             else:
-                h, Y1, part1, tpb1 = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank)
+                h, Y1, part1, tpb1 = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank, folded=folded)
                 values = None
         else:
             G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
@@ -1196,14 +1283,23 @@ class FusedCloudConditionNet:
         def fm_key(i, blk):
             return (i % (nlev + 1), blk.radius, blk.nsample)
 
+        first_main = FIRST_BALL_MAIN and LEVEL_EVENTS and not early and AHEAD_LEVEL > nlev
+        ev_first = None
+        if first_main:
+            # (embeddings first: three small launches during which the FPS kernel of the geometry stream takes its
+            # 32 workgroup slots; issued behind the ball query it waited for that kernel's 1000+ workgroups to drain)
+            self._embeddings(ts, label)
+            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
+            mark("main:first_ball_query_done")
         with torch.cuda.stream(side):
             mark("side:begin")
-            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
-            if AHEAD_LEVEL == 0:
-                xyz4(xyz)
-            mark("side:first_ball_query_done")
-            ev_first = torch.cuda.Event()
-            ev_first.record(side)
+            if not first_main:
+                fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
+                if AHEAD_LEVEL == 0:
+                    xyz4(xyz)
+                mark("side:first_ball_query_done")
+                ev_first = torch.cuda.Event()
+                ev_first.record(side)
             # Level by level, each with its own events: SA block i starts as soon as ITS sampling / grouping is
             # known, the feature-transfer block of level i + 1 as soon as its ball query is.  (One event after the
             # whole chain made the main stream sit idle from the end of the first feature-transfer block, 0.85 ms
@@ -1261,7 +1357,7 @@ class FusedCloudConditionNet:
             ev_knn.record(side)
 
         # ---- embeddings (A/B: PDR_EARLY_EMBED=0 issues them here, beside the running geometry stream)
-        if not early:
+        if not first_main and not early:
             self._embeddings(ts, label)
         mark("main:embeddings_done")
 
@@ -1292,7 +1388,8 @@ class FusedCloudConditionNet:
             return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
 
         # ---- feature path ------------------------------------------------------------------------
-        main.wait_event(ev_first)
+        if ev_first is not None:
+            main.wait_event(ev_first)
         mark("main:after_wait_first_ball_query")
         l_feat = [feat0]
         for i, sa in enumerate(self.sa):
@@ -1328,8 +1425,7 @@ class FusedCloudConditionNet:
         assert not ahead
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz4(xyz), 0, 3, 4, 1)], B * N, B, N)
-        Y, part, tpb = run_layer(head_in, self.head1, stats=True)
-        s, t = self.head_norm.fold([(part, 0, self.head1.Cout, tpb, 1.0)], B, self.head1.Cout, N)
+        Y, _, _, (s, t) = run_layer(head_in, self.head1, fold=FoldReq(self.head_norm, self.head1.Cout, N))
         out, _, _ = run_layer(Act([(Y, 0, self.head1.Cout, Y.shape[1], 1)], B * N, B, N, scale=s, shift=t,
                                   post_relu=True), self.head2)
         mark("main:head_done")

@@ -36,12 +36,20 @@ def batches(first, last, batch_size):
     return [(lo, min(lo + batch_size, last)) for lo in range(first, last, batch_size)]
 
 
-def evaluate_batch(generate, condition, label, gt, scale=1.0, f1_threshold=1e-4, compute_emd=True):
+def evaluate_batch(generate, condition, label, gt, scale=1.0, f1_threshold=1e-4, compute_emd=True, M_inv=None,
+                   translation=None):
     """One batch of the harness: `generate(condition, label)` -> (B,N,3) completed clouds.
+    M_inv (B,3,3) / translation (B,1,3): the inverse of the augmentation the dataset applied to condition and gt
+    (`augment_data_during_generation`, completion_eval.py:140-143): generated clouds and gt are mapped back with
+    `matmul(x - translation, M_inv)` before anything is measured (:203-205).
     Returns (generated/2/scale, records (B,5) = [cd_t, cd_p, f1, emd, label])."""
     from .chamfer_loss_new import calc_cd
     from .emd import earth_mover_distance
     generated = generate(condition, label)
+    if M_inv is not None:
+        shift = translation if translation is not None else torch.zeros_like(gt[:, :1])
+        generated = torch.matmul(generated - shift, M_inv)
+        gt = torch.matmul(gt - shift, M_inv)
     generated = generated / 2 / scale
     gt = gt / 2 / scale
     cd_p, cd_t, f1 = calc_cd(generated, gt, calc_f1=True, f1_threshold=f1_threshold)

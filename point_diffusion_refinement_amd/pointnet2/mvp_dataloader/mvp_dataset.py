@@ -14,9 +14,10 @@ Semantics kept from the reference:
     [26 r per, 26 (r+1) per) (:160-198); with `append_samples_to_last_rank` (training only) the short last rank is
     topped up with randomly drawn shapes (:171-196) -- generation passes False (generate_samples.py:191-192);
   * coordinates scaled by 2 * scale (the files hold [-0.5, 0.5]; mirrored files: xyz only, 4th channel = tag) (:250-262);
-  * items are dicts {'partial', 'complete', 'label'} (+ 'generated', 'XT' when requested).
-Training-time augmentation (mvp_data_utils.augment_cloud) is outside the generation path and not built:
-`augmentation` must be False.
+  * items are dicts {'partial', 'complete', 'label'} (+ 'generated', 'XT' when requested);
+  * `augmentation` (a dict, mvp_data_utils.augment_cloud) transforms every cloud of an item with ONE random
+    transform (:292-313); with `return_augmentation_params` the item carries 'M_inv' and 'translation' so that
+    the harness can map generated clouds back (completion_eval.py:140-143, 203-211).
 """
 import os
 import random
@@ -26,6 +27,7 @@ import numpy as np
 import torch
 import torch.utils.data as data
 
+from .mvp_data_utils import augment_cloud
 from .shard_io import load_array
 
 VIEWS = 26
@@ -38,8 +40,7 @@ class ShapeNetH5(data.Dataset):
                  randomly_select_generated_samples=False, use_mirrored_partial_input=False,
                  number_partial_points=2048, load_pre_computed_XT=False, T_step=100, XT_folder=None,
                  append_samples_to_last_rank=True):
-        if augmentation or return_augmentation_params:
-            raise NotImplementedError("training-time augmentation is not part of the generation path")
+        self.augmentation, self.return_augmentation_params = augmentation, return_augmentation_params
         if use_mirrored_partial_input or load_pre_computed_XT:
             assert novel_input and not novel_input_only
         split = "train" if train else "test"
@@ -145,12 +146,28 @@ class ShapeNetH5(data.Dataset):
 
     def __getitem__(self, index):
         gt_idx = self.partial_to_complete_index[index] if self.random_subsample else index // VIEWS
-        result = {"partial": torch.from_numpy(self.input_data[index].copy()),
-                  "complete": torch.from_numpy(self.gt_data[gt_idx].copy())}
+        result = {"partial": self.input_data[index].copy(), "complete": self.gt_data[gt_idx].copy()}
         if self.generated_sample is not None:
-            result["generated"] = torch.from_numpy(self.generated_sample[index].copy())
+            result["generated"] = self.generated_sample[index].copy()
         if self.generated_XT is not None:
-            result["XT"] = torch.from_numpy(self.generated_XT[index].copy())
+            result["XT"] = self.generated_XT[index].copy()
+        params = {}
+        if isinstance(self.augmentation, dict):
+            # one transform for every cloud of the item, in dict order (partial, complete, generated, XT)
+            clouds = list(result.values())
+            if self.return_augmentation_params:
+                clouds, params = augment_cloud(clouds, self.augmentation, return_augmentation_params=True)
+            else:
+                clouds = augment_cloud(clouds, self.augmentation, return_augmentation_params=False)
+            for key, cloud in zip(list(result.keys()), clouds):
+                result[key] = cloud
+            if self.generated_sample is not None:
+                sigma = self.augmentation.get("noise_magnitude_for_generated_samples", 0)
+                if sigma > 0:       # noise on the coarse cloud the refinement network is trained on (:305-313)
+                    noise = np.random.normal(scale=sigma, size=result["generated"].shape)
+                    result["generated"] = result["generated"] + noise.astype(result["generated"].dtype)
+        result.update(params)
+        result = {k: torch.from_numpy(v) for k, v in result.items()}
         result["label"] = self.labels[index]
         return result
 

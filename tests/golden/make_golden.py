@@ -197,6 +197,40 @@ def mirror():
     save("mirror.npz", partial=partial, both=both, down100=a, down256=b)
 
 
+def dataset():
+    """mvp_dataloader/mvp_dataset.py:16-328 (ShapeNetH5) on a tiny synthetic MVP directory: the REFERENCE reader's
+    arrays and items for the rank split of the test set (world_size 2, both ranks, short last rank), the mirrored
+    4-channel input, the topped-up last rank of the training set, random subsampling, scale != 1 and an augmented
+    item with its inverse-transform parameters; plus the de-augmentation of completion_eval.py:203-205 applied to a
+    synthetic generated batch.  The source arrays are stored too, so the test rebuilds the directory itself."""
+    import random
+    import tempfile
+    from tests.golden import dataset_inputs as DI
+    from point_diffusion_refinement_amd.pointnet2.mvp_dataloader import hdf5_io
+    from mvp_dataloader.mvp_dataset import ShapeNetH5
+    src = DI.source_arrays()
+    out = {"src_" + k: v for k, v in src.items()}
+    with tempfile.TemporaryDirectory() as root:
+        DI.write_directory(root, src, lambda path, arrays: hdf5_io.write(path, arrays))
+        for name, kw, seed in DI.CASES:
+            random.seed(seed), np.random.seed(seed)
+            ds = quiet(ShapeNetH5, root, **kw)
+            out[name + "_input"], out[name + "_gt"], out[name + "_labels"] = ds.input_data, ds.gt_data, ds.labels
+            out[name + "_len"] = np.array(len(ds))
+            if hasattr(ds, "partial_to_complete_index") and ds.random_subsample:
+                out[name + "_p2c"] = ds.partial_to_complete_index
+            for i in DI.item_indices(len(ds)):
+                random.seed(seed + i), np.random.seed(seed + i)
+                item = ds[i]
+                for k, v in item.items():
+                    out["%s_item%d_%s" % (name, i, k)] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    # de-augmentation exactly as completion_eval.py:203-205 writes it
+    gen, gt, M_inv, tr = DI.deaugment_inputs()
+    out["deaug_generated"] = torch.matmul(gen - tr, M_inv).numpy()
+    out["deaug_gt"] = torch.matmul(gt - tr, M_inv).numpy()
+    save("dataset.npz", **out)
+
+
 def state_dict_keys():
     from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
     net = PointNet2CloudCondition(R.load_config()['pointnet_config'])
@@ -215,4 +249,5 @@ if __name__ == "__main__":
     schedules()
     metrics()
     mirror()
+    dataset()
     state_dict_keys()

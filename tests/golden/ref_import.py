@@ -103,6 +103,61 @@ def install():
     emd.matchcost_forward = lambda a, b, m: _t(O.matchcost(_np(a), _np(b), _np(m)))
     emd.matchcost_backward = lambda g, a, b, m: [_t(x) for x in O.matchcost_grad(_np(g), _np(a), _np(b), _np(m))]
     sys.modules["emd_cuda"] = emd
+    # data path (mvp_dataloader/mvp_dataset.py imports h5py; mvp_data_utils imports transforms3d): h5py.File as a
+    # read-only view over libhdf5 through the product's ctypes binding -- what is being pinned is the READER's
+    # semantics (splits, scaling, item dicts), the file format itself is pinned by the h5import-written fixture --
+    # and the two transforms3d factors the augmentation uses, from their textbook definitions
+    from point_diffusion_refinement_amd.pointnet2.mvp_dataloader import hdf5_io
+
+    class _Dataset:
+        def __init__(self, path, name):
+            self._a = hdf5_io.read(path, name)
+            self.shape, self.dtype = self._a.shape, self._a.dtype
+
+        def __getitem__(self, key):
+            return self._a[key]
+
+        def __array__(self, dtype=None, copy=None):
+            return self._a if dtype is None else self._a.astype(dtype)
+
+        def __len__(self):
+            return len(self._a)
+
+    class _File:
+        def __init__(self, path, mode='r'):
+            assert mode == 'r', "stand-in h5py is read-only"
+            self._path = path
+
+        def __getitem__(self, name):
+            return _Dataset(self._path, name)
+
+        def close(self):
+            pass
+
+    h5 = types.ModuleType("h5py")
+    h5.File = _File
+    sys.modules["h5py"] = h5
+    t3 = types.ModuleType("transforms3d")
+    zooms, axangles = types.ModuleType("transforms3d.zooms"), types.ModuleType("transforms3d.axangles")
+
+    def zfdir2mat(zfactor, direction=None):
+        if direction is None:
+            return np.diag([zfactor] * 3).astype(np.float64)
+        n = np.asarray(direction, dtype=np.float64)
+        n = n / np.linalg.norm(n)
+        return np.eye(3) - (1 - zfactor) * np.outer(n, n)
+
+    def axangle2mat(axis, angle):
+        x, y, z = np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis)
+        c, s = np.cos(angle), np.sin(angle)
+        C = 1 - c
+        return np.array([[x * x * C + c, x * y * C - z * s, x * z * C + y * s],
+                         [y * x * C + z * s, y * y * C + c, y * z * C - x * s],
+                         [z * x * C - y * s, z * y * C + x * s, z * z * C + c]])
+    zooms.zfdir2mat, axangles.axangle2mat = zfdir2mat, axangle2mat
+    t3.zooms, t3.axangles = zooms, axangles
+    for name, mod in [("transforms3d", t3), ("transforms3d.zooms", zooms), ("transforms3d.axangles", axangles)]:
+        sys.modules[name] = mod
     # CPU-only container: .cuda() is the identity, tensors report is_cuda for emd.py's assert
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self

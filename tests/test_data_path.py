@@ -35,6 +35,31 @@ def test_hdf5_round_trip_and_format(tmp_path):
         shard_io.load_array(str(tmp_path / "nope.h5"), "data")
 
 
+@pytest.mark.skipif(not hdf5_io.available(), reason="libhdf5 not present")
+def test_reads_a_file_written_by_the_hdf_groups_h5import(tmp_path):
+    """tests/golden/h5/h5import_written.h5 was produced by `h5import` (HDF Group command-line tool, make_fixture.sh),
+    not by this repo: contiguous float32 / int64 datasets and a chunked, gzip-compressed float64 dataset in a group.
+    And the other direction where the tools exist: a file written here is listed and dumped correctly by h5ls / h5dump."""
+    import shutil
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5")
+    want = np.load(os.path.join(d, "expect.npz"))
+    path = os.path.join(d, "h5import_written.h5")
+    for name, key in (("incomplete_pcds", "incomplete_pcds"), ("labels", "labels"), ("group/data", "data")):
+        got = hdf5_io.read(path, name)
+        assert got.dtype == want[key].dtype and np.array_equal(got, want[key]), name
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        mine = str(tmp_path / "mine.h5")
+        a = (np.arange(24, dtype=np.float32) / 8 - 1).reshape(2, 4, 3)
+        hdf5_io.write(mine, {"complete_pcds": a, "labels": np.array([7, -1], np.int64)})
+        text = subprocess.run([h5dump, "-d", "/complete_pcds", "-y", "-w", "0", mine], capture_output=True, text=True).stdout
+        assert "H5T_IEEE_F32LE" in text and "( 2, 4, 3 )" in text
+        body = text[text.index("DATA {") + 6:text.rindex("}")]
+        vals = np.array([float(v) for v in body.replace("}", " ").replace("\n", " ").split(",") if v.strip()], np.float32)
+        assert np.array_equal(vals, a.reshape(-1))
+
+
 def test_npz_fallback_is_transparent(tmp_path):
     a = np.arange(24, dtype=np.float32).reshape(2, 4, 3)
     shard_io.save_arrays(str(tmp_path / "y.npz"), {"data": a})
@@ -83,8 +108,6 @@ def test_dataset_matches_reference_semantics(tmp_path):
     assert cond.shape == (20, 48, 3) and label.dtype == torch.int64
     assert torch.equal(gtb[0], torch.from_numpy(parts[1].gt_data[20 // 26])) and \
         torch.equal(gtb[-1], torch.from_numpy(parts[1].gt_data[39 // 26]))
-    with pytest.raises(NotImplementedError):
-        ShapeNetH5(root, train=False, npoints=64, augmentation={"pc_augm_scale": 1.2})
 
 
 def test_mirrored_partials_feed_the_dataset(tmp_path):
@@ -128,3 +151,61 @@ def test_rank_results_gather_equals_concatenation(tmp_path):
         assert set(pickle.load(h)) == {"meta", "cd_distance", "emd_distance", "f1", "avg_cd", "avg_emd", "iter"}
     assert os.listdir(os.path.join(root, "rank_0")) == []                     # originals removed
     assert "CD loss" in open(os.path.join(root, "gathered_generation.log")).read()
+
+
+# ------------------------------------------------------------------ pinned against the REFERENCE reader
+def test_shapenet_h5_equals_the_reference_reader(tmp_path):
+    """tests/golden/dataset.npz was produced by the reference's own mvp_dataset.ShapeNetH5 (imported in the build
+    container over stand-ins for h5py / transforms3d, tests/golden/make_golden.py dataset()) on the tiny synthetic MVP
+    directory rebuilt here: rank splits incl. the short last rank, the mirrored 4-channel input, the topped-up last
+    training rank (same `random.sample` draws), random subsampling, novel-only, scale != 1, and an augmented item
+    with M_inv / translation -- arrays and items bit for bit."""
+    import random
+    from tests.golden import dataset_inputs as DI
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz"))
+    src = {k[4:]: g[k] for k in g.files if k.startswith("src_")}
+    for k, v in DI.source_arrays().items():                              # the committed inputs are the seeded ones
+        assert np.array_equal(src[k], v), k
+    ext = EXT
+    DI.write_directory(str(tmp_path), src, lambda path, arrays: shard_io.save_arrays(path[:-3] + ext, arrays))
+    for name, kw, seed in DI.CASES:
+        random.seed(seed), np.random.seed(seed)
+        ds = ShapeNetH5(str(tmp_path), **kw)
+        assert len(ds) == int(g[name + "_len"]), name
+        for attr, key in (("input_data", "_input"), ("gt_data", "_gt"), ("labels", "_labels")):
+            got, want = getattr(ds, attr), g[name + key]
+            assert got.shape == want.shape and np.array_equal(got, want), (name, attr)
+            assert got.dtype == want.dtype or attr == "labels", (name, attr, got.dtype, want.dtype)
+        if name + "_p2c" in g.files:
+            assert np.array_equal(ds.partial_to_complete_index, g[name + "_p2c"])
+        for i in DI.item_indices(len(ds)):
+            random.seed(seed + i), np.random.seed(seed + i)
+            item = ds[i]
+            keys = sorted(k.split("_item%d_" % i)[1] for k in g.files if k.startswith("%s_item%d_" % (name, i)))
+            assert sorted(item.keys()) == keys, (name, i, sorted(item.keys()), keys)
+            for k in keys:
+                want = g["%s_item%d_%s" % (name, i, k)]
+                got = item[k].numpy() if torch.is_tensor(item[k]) else np.asarray(item[k])
+                assert got.shape == want.shape and np.array_equal(got, want), (name, i, k)
+    assert (g["test_w2_r1_len"], g["test_w2_r0_len"]) == (3 * 26, 4 * 26)      # the last rank IS short
+    assert "test_augmented_item0_M_inv" in g.files and g["train_w2_r1_append_len"] == 4 * 26
+
+
+def test_deaugmentation_of_generated_clouds_matches_the_reference_harness(monkeypatch):
+    """generation.evaluate_batch(M_inv=, translation=): completion_eval.py:203-205 `matmul(x - translation, M_inv)`
+    on generated clouds AND ground truth before the /2/scale and the metrics (golden from the reference expression)."""
+    from tests.golden import dataset_inputs as DI
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz"))
+    gen, gt, M_inv, tr = DI.deaugment_inputs()
+    seen = {}
+
+    def fake_cd(generated, gtt, calc_f1=True, f1_threshold=1e-4):
+        seen["generated"], seen["gt"] = generated.clone(), gtt.clone()
+        z = torch.zeros(generated.shape[0])
+        return z, z, z
+    from point_diffusion_refinement_amd.pointnet2 import chamfer_loss_new
+    monkeypatch.setattr(chamfer_loss_new, "calc_cd", fake_cd)
+    out, rec = G.evaluate_batch(lambda c, l: gen, None, torch.zeros(3, dtype=torch.long), gt, scale=0.5, compute_emd=False,
+                                M_inv=M_inv, translation=tr)
+    assert np.array_equal(out.numpy(), g["deaug_generated"] / 2 / 0.5)
+    assert np.array_equal(seen["gt"].numpy(), g["deaug_gt"] / 2 / 0.5) and rec.shape == (3, 5)

@@ -123,6 +123,53 @@ def test_native_step_embedding_chain_equals_the_torch_chain(cuda, monkeypatch):
     net.global_feature = None
 
 
+@pytest.mark.parametrize("B,rpb,Cin,Cout,Cn", [(3, 256, 40, 64, 64), (32, 512, 96, 512, 512), (5, 2048, 64, 79, 64),
+                                               (64, 128, 32, 96, 96), (2, 8192, 32, 128, 128)])
+def test_in_launch_groupnorm_fold_equals_the_separate_fold(cuda, B, rpb, Cin, Cout, Cn, monkeypatch):
+    """pdr_fused_layer_fold (csrc/gn_tail_fold.h): the workgroup completing a batch element folds it.  Same scale /
+    shift as pdr_fused_layer + pdr_gn_fold (double sums in a different fixed order: 1e-6), tickets left at zero, a
+    second launch on the same tickets gives the same bits; also the two-source form (q half counted K times + key
+    half from another launch) of the attention score GroupNorm, and MyGroupNorm's pass-through channels."""
+    from point_diffusion_refinement_amd.pointnet2_ops.attention import MyGroupNorm
+    g = torch.Generator().manual_seed(B + rpb + Cout)
+    x = (torch.randn(B * rpb, Cin, generator=g) * 1.5 + 0.3).to(cuda)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    conv = _conv(W, torch.randn(Cout, generator=g).to(cuda))
+    norm = FN.Norm(fill_deterministic(MyGroupNorm(32, Cout), 3).to(cuda))
+    assert norm.Cn == Cn
+    act = FN.plain(x, B, rpb)
+    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 0)
+    Y0, p0, tpb, (s0, t0) = FN.run_layer(act, conv, fold=FN.FoldReq(norm, Cout, rpb))
+    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 1 << 20)
+    plan = (ctypes.c_int * 7)()
+    li = act.struct()
+    _lib.check(_lib.load().pdr_fused_layer_plan(ctypes.byref(li), act.P, Cin, conv.Wt.data_ptr(), conv.ldw, Cout, None,
+                                                FN._ldy(Cout), plan), "plan")
+    for it in range(2):
+        Y1, p1, _, (s1, t1) = FN.run_layer(act, conv, fold=FN.FoldReq(norm, Cout, rpb))
+        assert torch.equal(Y0, Y1) and torch.equal(p0, p1)
+        np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(t1.cpu().numpy(), t0.cpu().numpy(), rtol=2e-6, atol=2e-6)
+        if plan[0]:                                                       # wave-specialised kernel: fold in the launch
+            assert int(norm.tickets(B).abs().sum()) == 0
+        if it == 0:
+            first = (s1.clone(), t1.clone())
+    assert torch.equal(first[0], s1) and torch.equal(first[1], t1)
+    # two sources: [this layer's first 32 columns counted K = 8 times | columns 8.. of another launch's moments]
+    K, C2 = 8, 32
+    x2 = torch.randn(B * rpb * K, 16, generator=g).to(cuda)
+    conv2 = _conv((torch.randn(C2 + 8, 16, generator=g) / 4).to(cuda), torch.zeros(C2 + 8, device=cuda))
+    _, p2, tpb2 = FN.run_layer(FN.plain(x2, B, rpb * K), conv2, stats=True)
+    n1 = FN.Norm(fill_deterministic(MyGroupNorm(32, 32 + C2), 4).to(cuda))
+    req = lambda: FN.FoldReq(n1, 32, rpb * K, mult0=float(K), second=(p2, 8, C2, tpb2, 1.0))
+    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 0)
+    _, _, _, (sa, ta) = FN.run_layer(act, conv, fold=req())
+    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 1 << 20)
+    _, _, _, (sb, tb) = FN.run_layer(act, conv, fold=req())
+    np.testing.assert_allclose(sb.cpu().numpy(), sa.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
 def test_groupnorm_fold_matches_torch_groupnorm(cuda):
     g = torch.Generator().manual_seed(3)
     B, rpb, C = 3, 256, 79                                               # MyGroupNorm(32, 79): 64 normalised + 15 pass-through
