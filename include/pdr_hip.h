@@ -355,37 +355,6 @@ int pdr_reverse_step(float *x, const float *eps, int ld_eps, const float *z, con
                      const float *tab_b, const float *tab_c, long long *t_dev, const float *ts_table,
                      float *ts_out, unsigned long long *rng_state, int *ticket, long npoints, int mode,
                      pdr_stream_t stream);
-/* ---- GroupNorm fold carried by the launch that produces the statistics ---------------------------------
- * MyGroupNorm / nn.GroupNorm between two convs (pointnet2_modules.py:23-40, 42-67) needs per-(batch element,
- * channel) moments of the producing conv's output.  pdr_gn_fold turns the per-tile partial moments into
- * scale = rstd gamma, shift = beta - mean scale in a launch of its own; with a pdr_fold_t the producing launch
- * (pdr_fused_layer_fold / pdr_gather_add_fold) does it itself: the workgroup that completes a batch element folds it
- * (device tickets, no grid-wide wait; csrc/gn_tail_fold.h).  Same result definition as pdr_gn_fold (double sums,
- * fixed order).  Channels = [own statistics columns col0 .. col0+C0) | first C1 columns of `part1`] (part1 NULL:
- * C1 = 0), the first Cn of them normalised in G groups, the rest pass through (scale 1, shift 0). */
-typedef struct {
-  int *ticket;              /* nB zero-initialised ints; left zero by every launch */
-  const float *gamma, *beta;
-  float *scale, *shift;     /* (nB, C0 + C1) */
-  const float *part1;       /* second statistics source (nB * tpb1, ldp1, 2) or NULL */
-  double mult0, mult1;      /* multiplicity of a source row (a per-query conv broadcast to K positions: K) */
-  double n;                 /* elements per channel and batch element */
-  int col0, C0;
-  int ldp1, tpb1, C1;
-  int Cn, G;
-  float eps;
-} pdr_fold_t;
-/* pdr_fused_layer / pdr_gather_add with the GroupNorm fold of the statistics they produce (`partial` required).
- * PDR_EUNSUPPORTED (nothing launched): no kernel with a fold tail for this launch shape, or more than 64 batch
- * elements -- the caller uses the plain entry point followed by pdr_gn_fold. */
-int pdr_fused_layer_fold(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
-                         const float *bias, int Cout, float *Y, int ldy, float *partial, int relu_col0,
-                         const pdr_fold_t *fold, pdr_stream_t stream);
-int pdr_gather_add_fold(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,
-                        const int *idx, const int *counts, const float *s1, const float *r1,
-                        const float *s2, const float *r2, int B, int rows_per_batch, int K, int Cout,
-                        float *Y, int ldy, float *partial, int relu_col0, int ycol0, int ycols,
-                        const pdr_fold_t *fold, pdr_stream_t stream);
 /* ---- step embedding chain -------------------------------------------------------
  * out (B,N; ld ldo) = act(bias + in . W^T), W (N,K) row-major as nn.Linear stores it, act 0 = none, 1 = swish
  * (x sigmoid(x)).  in = x (B,K; ld ldx) when ts == NULL, else the sinusoidal step embedding of
@@ -397,6 +366,11 @@ int pdr_gather_add_fold(const float *U, int ldu, int n_src, const float *V, cons
 int pdr_embed_linear(const float *x, int ldx, const float *ts, int ts_stride, const float *freq, int half,
                      const float *W, const float *bias, int B, int K, int N, int act, float *out, int ldo,
                      pdr_stream_t stream);
+/* out (B,m,C0+C1) = rows idx (B,m) of the channel-last concatenation [src0 (B,n,C0) | src1 (B,n,C1)] without
+ * building it (the `torch.cat([mapped, features], 1)` + gather_operation of pointnet2_with_pcld_condition.py
+ * :392-398 and pointnet2_modules.py:243-246 in one launch) */
+int pdr_gather_rows2(const float *src0, int C0, const float *src1, int C1, const int *idx, int B, int n, int m,
+                     float *out, pdr_stream_t stream);
 /* out (rows, ldo) = [src (rows, C) | 0]: channel-last rows padded to a 16-byte multiple (the layer kernels stage
  * rows with 16-byte loads; replaces F.pad's fill + strided copy) */
 int pdr_pad_rows(const float *src, long rows, int C, float *out, int ldo, pdr_stream_t stream);

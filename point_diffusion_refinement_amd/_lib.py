@@ -58,10 +58,8 @@ SIGNATURES = {
     "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_reverse_update": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
     "pdr_reverse_step": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
+    "pdr_gather_rows2": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "pdr_pad_rows": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
-    "pdr_fused_layer_fold": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
-    "pdr_gather_add_fold": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I,
-                                 _P, _P]),
     "pdr_mark_time": (_I, [_P, _P]),
     "pdr_embed_linear": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_gather_add": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
@@ -71,13 +69,6 @@ SIGNATURES = {
 class Seg(_c.Structure):
     _fields_ = [("ptr", _P), ("C", _I), ("ld", _I), ("row_div", _I), ("gV", _P), ("gV0", _P), ("g_ldv", _I),
                 ("g_nsrc", _I), ("g_zrow", _I), ("g_reserved", _I), ("g_r1", _P), ("g_r2", _P)]
-
-
-class Fold(_c.Structure):
-    """pdr_fold_t of include/pdr_hip.h."""
-    _fields_ = [("ticket", _P), ("gamma", _P), ("beta", _P), ("scale", _P), ("shift", _P), ("part1", _P),
-                ("mult0", _c.c_double), ("mult1", _c.c_double), ("n", _c.c_double), ("col0", _I), ("C0", _I),
-                ("ldp1", _I), ("tpb1", _I), ("C1", _I), ("Cn", _I), ("G", _I), ("eps", _F)]
 
 
 class LayerIn(_c.Structure):

@@ -447,10 +447,14 @@ extern "C" int pdr_furthest_point_sampling(const float* xyz, int B, int N, int m
   // 0 = never, 2 = for every size up to 4096 slots (A/B and test runs).
   static const int wave_mode = []() {
     const char* e = getenv("PDR_FPS_WAVE");
-    return e ? atoi(e) : 1;
+    // only "0", "1", "2" are meaningful; anything else keeps the default instead of silently disabling the path
+    return (e && (e[0] == '0' || e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 1;
   }();
   const bool use_wave = wave_mode == 2 || (wave_mode == 1 && static_cast<long>(R) * Q <= 256);
-  if (use_wave && static_cast<long>(R) * Q <= 4096) {
+  // the wave kernel keeps the cloud in N * 16 bytes of dynamic LDS next to its static exchange slots: stay inside
+  // the 64 KiB a launch gets without raising hipFuncAttributeMaxDynamicSharedMemorySize, else the resident kernel
+  const bool wave_fits = static_cast<size_t>(N) * sizeof(float4) + 256 <= 64 * 1024;
+  if (use_wave && wave_fits && static_cast<long>(R) * Q <= 4096) {
     // rank-ordered slots + packed distances + tree arg-max (fps_wave_kernel): ONE wave while a lane holds <= 4
     // slots (no barrier at all), four waves (one per SIMD: a single wave issues at most one instruction every
     // ~4-5 cycles, measured 680 ns per round with 32 slots per lane) above that

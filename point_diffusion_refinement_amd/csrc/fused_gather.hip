@@ -14,7 +14,6 @@
 // All tensors channel-LAST: a position's channels are contiguous, so neighbour feature rows are
 // read as whole contiguous segments and every store is coalesced.
 #include "pdr_common.h"
-#include "gn_tail_fold.h"
 
 namespace {
 
@@ -238,6 +237,22 @@ __global__ __launch_bounds__(256) void gather_rows_cl_kernel(const float* __rest
   out[e] = src[(static_cast<long>(b) * n + idx[bj]) * C + c];
 }
 
+// out[b, j, :] = [src0[b, idx[b,j], :] | src1[b, idx[b,j], :]]: gather of the rows of a concatenation that is never
+// materialised (torch.cat + gather_rows as one launch)
+__global__ __launch_bounds__(256) void gather_rows2_cl_kernel(const float* __restrict__ src0, int C0,
+                                                              const float* __restrict__ src1, int C1, int n,
+                                                              const int* __restrict__ idx, int m, long total,
+                                                              float* __restrict__ out) {
+  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int C = C0 + C1;
+  const long bj = e / C;
+  const int c = static_cast<int>(e - bj * C);
+  const int b = static_cast<int>(bj / m);
+  const long row = static_cast<long>(b) * n + idx[bj];
+  out[e] = c < C0 ? src0[row * C0 + c] : src1[row * C1 + (c - C0)];
+}
+
 // rows of C floats -> rows of ldo >= C floats, zero-filled behind column C (F.pad as ONE launch: torch pads with a
 // fill plus a strided copy)
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int C, int ldo, long total,
@@ -341,6 +356,17 @@ extern "C" int pdr_attention_pool(const float* scores, int lds, const float* val
   return pdr::check_launch();
 }
 
+extern "C" int pdr_gather_rows2(const float* src0, int C0, const float* src1, int C1, const int* idx, int B, int n,
+                                int m, float* out, pdr_stream_t stream) {
+  if (B < 0 || n <= 0 || C0 <= 0 || C1 <= 0 || m < 0) return PDR_EINVAL;
+  if (B == 0 || m == 0) return PDR_OK;
+  if (!src0 || !src1 || !idx || !out) return PDR_EINVAL;
+  const long total = static_cast<long>(B) * m * (C0 + C1);
+  hipLaunchKernelGGL(gather_rows2_cl_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream), src0,
+                     C0, src1, C1, n, idx, m, total, out);
+  return pdr::check_launch();
+}
+
 extern "C" int pdr_pad_rows(const float* src, long rows, int C, float* out, int ldo, pdr_stream_t stream) {
   if (rows < 0 || C <= 0 || ldo < C) return PDR_EINVAL;
   if (rows == 0) return PDR_OK;
@@ -388,7 +414,7 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
     const float* __restrict__ s1, const float* __restrict__ r1, const float* __restrict__ s2,
     const float* __restrict__ r2, int rows_per_batch, int K, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int ycol0, int ycol1, pdr_fold_t fold) {
+    float* __restrict__ partial, int relu_col0, int ycol0, int ycol1) {
   constexpr int TM = 128;
   constexpr int RPI = 64 / LPR;            // rows per wave instruction
   // row groups in flight per iteration: the kernel is bound by the latency of its L2 gathers, so every wave keeps
@@ -507,17 +533,12 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
                          (red[2][threadIdx.x][0] + red[3][threadIdx.x][0]);
         const float t2 = (red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) +
                          (red[2][threadIdx.x][1] + red[3][threadIdx.x][1]);
-        pdr::store_partial(partial + (static_cast<long>(bid) * Cout + cc2) * 2, t1, t2);
+        float* o = partial + (static_cast<long>(bid) * Cout + cc2) * 2;
+        o[0] = t1;
+        o[1] = t2;
       }
       __syncthreads();
     }
-  }
-  // GroupNorm fold of the statistics by the workgroup that completes a batch element (gn_tail_fold.h): this
-  // workgroup produced exactly one row tile of batch element b
-  if (fold.ticket != nullptr) {   // uniform
-    __shared__ double fold_lds[4 * 256 + 2];
-    auto units = [&](int bb) -> int { return bb == b ? 1 : 0; };
-    pdr::tail_fold<256>(fold, partial, Cout, tpb, static_cast<int>(gridDim.x) / tpb, tpb, units, fold_lds);
   }
 }
 
@@ -529,23 +550,6 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
                               const float* r1, const float* s2, const float* r2, int B,
                               int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
                               int relu_col0, int ycol0, int ycols, pdr_stream_t stream) {
-  return pdr_gather_add_fold(U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2, B, rows_per_batch, K, Cout, Y,
-                             ldy, partial, relu_col0, ycol0, ycols, nullptr, stream);
-}
-
-// pdr_gather_add + the GroupNorm fold of its statistics (pdr_fold_t, include/pdr_hip.h) in the same launch
-extern "C" int pdr_gather_add_fold(const float* U, int ldu, int n_src, const float* V, const float* V0,
-                                   int ldv, const int* idx, const int* counts, const float* s1,
-                                   const float* r1, const float* s2, const float* r2, int B,
-                                   int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
-                                   int relu_col0, int ycol0, int ycols, const pdr_fold_t* fold,
-                                   pdr_stream_t stream) {
-  pdr_fold_t fd = pdr_fold_t();
-  if (fold) {
-    const int rc = pdr::check_fold(*fold, partial, Cout, B);
-    if (rc != PDR_OK) return rc;
-    fd = *fold;
-  }
   if (!U || !V || !idx || (!Y && !partial) || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 ||
       n_src <= 0)
     return PDR_EINVAL;
@@ -569,7 +573,7 @@ extern "C" int pdr_gather_add_fold(const float* U, int ldu, int n_src, const flo
 #define PDR_GA_K(LPR, KP, HS)                                                                          \
   hipLaunchKernelGGL((gather_add_kernel<LPR, KP, HS>), grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
                      counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0, ycol0, \
-                     ycol0 + y4, fd)
+                     ycol0 + y4)
 #define PDR_GA(LPR)                                       \
   do {                                                    \
     if (kpow2 && has_s) PDR_GA_K(LPR, true, true);        \

@@ -30,7 +30,6 @@
 // 4 (Cin + Cout) bytes per position for 2 Cin Cout flops: 5-20 flop/B, i.e. HBM-bound
 // (machine balance ~25 flop/B at the 157 TF fp32-MFMA peak).
 #include "pdr_common.h"
-#include "gn_tail_fold.h"
 
 #include <cstdlib>
 
@@ -974,22 +973,10 @@ extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, c
 extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
                                const float* bias, int Cout, float* Y, int ldy, float* partial,
                                int relu_col0, pdr_stream_t stream) {
-  return pdr_fused_layer_fold(in, P, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nullptr, stream);
-}
-
-// pdr_fused_layer + the GroupNorm fold of its statistics in the same launch (wave-specialised kernels only)
-extern "C" int pdr_fused_layer_fold(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
-                                    const float* bias, int Cout, float* Y, int ldy, float* partial,
-                                    int relu_col0, const pdr_fold_t* fold, pdr_stream_t stream) {
   if (!Y) return PDR_EINVAL;
   LayerPlan pl;
   const int prc = plan_layer(in, P, Cin, Wt, ldw, Cout, Y, ldy, &pl);
   if (prc != PDR_OK) return prc;
-  if (fold) {
-    const int frc = pdr::check_fold(*fold, partial, Cout, static_cast<int>(P / in->rows_per_batch));
-    if (frc != PDR_OK) return frc;
-    if (!pl.ws || (pl.thin && !partial)) return PDR_EUNSUPPORTED;
-  }
   if (P == 0) return PDR_OK;
   const TileCfg t = pl.t;
   const bool vec = pl.vec, gath = pl.gath, radd = pl.radd;
@@ -1015,9 +1002,8 @@ extern "C" int pdr_fused_layer_fold(const pdr_layer_in_t* in, long P, int Cin, c
   }
   if (pl.ws &&
       pdr::launch_fused_layer_ws(t.id, radd, gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt,
-                                 ncol, s, false, nullptr, fold))
+                                 ncol, s))
     return pdr::check_launch();
-  if (fold) return PDR_EUNSUPPORTED;   // (no wave-specialised instantiation after all)
   // kNN-form gathered sources exist in the wave-specialised kernel only: the caller materialises instead
   if (pl.knn) return PDR_EUNSUPPORTED;
 #define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC, GATH)                                            \

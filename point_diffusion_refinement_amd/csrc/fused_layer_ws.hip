@@ -24,7 +24,6 @@
 #include <cstdlib>
 
 #include "pdr_common.h"
-#include "gn_tail_fold.h"
 
 #include <type_traits>
 
@@ -100,7 +99,7 @@ template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool 
 __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int n_row_tiles, pdr_fold_t fold, pdr::PoolArgs pool) {
+    float* __restrict__ partial, int relu_col0, int n_row_tiles, pdr::PoolArgs pool) {
   // SPLIT: `Wt` points at the packed bf16 hi / lo weight image (pdr_pack_weights_bf16x3: per column block and
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
@@ -158,24 +157,6 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     c.tile = really ? n.tile : c.tile;
   };
   auto last_of_tile = [&](const Cur& c) { return c.sg == in.n_seg - 1 && c.ks + KC >= in.seg[c.sg].C; };
-
-  // GroupNorm fold of this layer's statistics by the workgroup that completes a batch element (gn_tail_fold.h);
-  // reached by all eight waves after their loops, the dead staging buffers serve as scratch
-  auto tail = [&]() __attribute__((always_inline)) {
-    if constexpr (!POOL) {
-      if (fold.ticket != nullptr) {   // uniform
-        const int bid = static_cast<int>(blockIdx.x);
-        auto units = [&](int b) -> int {   // this workgroup's row tiles bid + k nwg, k < my_tiles, inside batch element b
-          const int lo = b * tpb, hi = lo + tpb;
-          const int k0 = lo > bid ? (lo - bid + nwg - 1) / nwg : 0;
-          const int k1 = hi > bid ? (hi - bid + nwg - 1) / nwg : 0;
-          return max(0, min(k1, my_tiles) - min(k0, my_tiles));
-        };
-        pdr::tail_fold<512>(fold, partial, Cout, tpb, n_row_tiles / tpb, tpb * static_cast<int>(gridDim.y), units,
-                            reinterpret_cast<double*>(&sm));
-      }
-    }
-  };
 
   if (wave >= 4) {
     // =================================== PRODUCERS ===================================
@@ -556,7 +537,6 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
       PDR_T(1, 4 * g + 2);
       __syncthreads();                                 // B(g): stage g full, stage g+1 free
     }
-    tail();
     return;
   }
 
@@ -892,7 +872,9 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
                 s1 += red[w][c][0];
                 s2 += red[w][c][1];
               }
-              pdr::store_partial(partial + (static_cast<long>(tile) * Cout + n0 + c) * 2, s1, s2);
+              float* o = partial + (static_cast<long>(tile) * Cout + n0 + c) * 2;
+              o[0] = s1;
+              o[1] = s2;
             }
           }
         }
@@ -901,7 +883,6 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
     PDR_T(0, 4 * g + 3);
     advance(cur);
   }
-  tail();
 }
 
 }  // namespace
@@ -955,14 +936,11 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
 // block); instantiated for the 128-column tile variants 4 and 5 only.
 bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
                            int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
-                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split, const PoolArgs* pool,
-                           const pdr_fold_t* fold) {
+                           int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split, const PoolArgs* pool) {
   if (!fused_layer_ws_supported(id, radd, gath, in, Cin)) return false;
   if (split && id != 4 && id != 5) return false;
   if (pool && (radd || gath || split || in.oadd)) return false;   // pooled epilogue: plain sources, exact arithmetic
   const PoolArgs pa = pool ? *pool : PoolArgs();
-  pdr_fold_t fd = pdr_fold_t();
-  if (fold && partial && !pool) fd = *fold;
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   const long cap = (512 + ncol - 1) / ncol;
@@ -970,10 +948,10 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, fd, pa)
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
 #define PDR_WS_POOL(RT, CT, WR, WC, KC)                                                                       \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, fd, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   const bool knn_res = in.rseg.gV && in.rseg.g_r1;

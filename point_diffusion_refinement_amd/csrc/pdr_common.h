@@ -46,7 +46,7 @@ bool fused_layer_ws_supported(int variant, bool radd, bool gath, const pdr_layer
 bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,
                            const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
                            float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s,
-                           bool split = false, const PoolArgs* pool = nullptr, const pdr_fold_t* fold = nullptr);
+                           bool split = false, const PoolArgs* pool = nullptr);
 
 // ---- DPP wave reductions (wave64, gfx9 row_shr / row_bcast) -------------------
 // After wave_max_*: lane 63 holds the maximum; callers broadcast with readlane.

@@ -97,8 +97,13 @@ class GradientAllReduce:
             flat, items = self.buckets[bi]
             flat.div_(self.world)
             for p, off, n in items:
+                avg = flat.narrow(0, off, n).view_as(p)
                 if p.grad is not None:
-                    p.grad.copy_(flat.narrow(0, off, n).view_as(p.grad))
+                    p.grad.copy_(avg)
+                else:
+                    # no local gradient, but another rank may have produced one: every rank must apply the SAME
+                    # averaged gradient or the replicas diverge at the next optimizer step
+                    p.grad = avg.clone()
         self._handles = []
         self._pending = [len(items) for _, items in self.buckets]
         self._queued = False

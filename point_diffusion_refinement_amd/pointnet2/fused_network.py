@@ -80,18 +80,9 @@ EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
 # Geometry prepass: one event per level instead of one after the whole chain (see _forward_cached).
 # PDR_LEVEL_EVENTS=0 restores the single wait (A/B).
 LEVEL_EVENTS = __import__("os").environ.get("PDR_LEVEL_EVENTS", "1") == "1"
-# Start of a step: the geometry stream begins with the FPS chain (the longest dependency chain of the step: with one
-# event per level it decides when SA block 0 can start); the first feature-transfer block's ball query runs on the
-# MAIN stream and the step embeddings beside it on the auxiliary stream.  PDR_FIRST_BALL_MAIN=0: ball query first on the
-# geometry stream, embeddings on the main stream (A/B).
-FIRST_BALL_MAIN = __import__("os").environ.get("PDR_FIRST_BALL_MAIN", "1") == "1"
 # Step-embedding chain (sin / cos, fc_t1, swish, fc_t2, swish, every block's fc(t_emb)) as three pdr_embed_linear
 # launches instead of ~12 torch / hipBLASLt ones.  PDR_NATIVE_EMBED=0: the torch chain (A/B, cross-check).
 NATIVE_EMBED = __import__("os").environ.get("PDR_NATIVE_EMBED", "1") == "1"
-# GroupNorm folds carried by the launch that produces the statistics (pdr_fused_layer_fold / pdr_gather_add_fold,
-# csrc/gn_tail_fold.h) instead of a pdr_gn_fold launch of their own, when the workgroup that completes a batch element
-# has at most PDR_FOLD_TAIL_KB KiB of partial moments to read (0 = always a separate launch).
-FOLD_TAIL_KB = int(__import__("os").environ.get("PDR_FOLD_TAIL_KB", "0"))
 
 
 def _stream():
@@ -366,8 +357,11 @@ def _ldy(Cout):
 
 
 class FoldReq:
-    """GroupNorm fold requested together with the launch that produces its statistics: channels = columns
-    [col0, col0 + C0) of that launch's output (+ the first columns of `second` = (partial, col0, C, tpb, mult))."""
+    """The GroupNorm fold that follows a layer, requested together with the layer: channels = columns
+    [col0, col0 + C0) of that layer's output (+ the first columns of `second` = (partial, col0, C, tpb, mult)).
+    (Round 3 carried such folds inside the producing launch -- per-batch-element device tickets, the completing
+    workgroup folds -- and measured it slower at every size; the request object stayed because it keeps
+    the producer and its GroupNorm in one place.)"""
 
     def __init__(self, norm, C0, n, col0=0, mult0=1.0, second=None):
         self.norm, self.C0, self.n, self.col0, self.mult0, self.second = norm, C0, n, col0, mult0, second
@@ -376,29 +370,8 @@ class FoldReq:
     def C(self):
         return self.C0 + (self.second[2] if self.second else 0)
 
-    def in_launch(self, B, tpb):
-        """Carry the fold in the producing launch?  (the workgroup completing a batch element reads tpb x C moments)"""
-        tiles = max(tpb, self.second[3] if self.second else 0)
-        return FOLD_TAIL_KB > 0 and B <= 64 and tiles * self.C * 8 <= FOLD_TAIL_KB * 1024
-
-    def struct(self, B, dev):
-        norm, C = self.norm, self.C
-        scale = torch.empty((B, C), dtype=torch.float32, device=dev)
-        shift = torch.empty((B, C), dtype=torch.float32, device=dev)
-        f = _lib.Fold()
-        f.ticket = norm.tickets(B).data_ptr()
-        f.gamma, f.beta = norm.gamma.data_ptr(), norm.beta.data_ptr()
-        f.scale, f.shift = scale.data_ptr(), shift.data_ptr()
-        f.mult0, f.mult1, f.n = float(self.mult0), 1.0, float(self.n)
-        f.col0, f.C0 = self.col0, self.C0
-        if self.second:
-            pb, cb, nb, tb, mb = self.second
-            f.part1, f.ldp1, f.tpb1, f.C1, f.mult1 = _ptr(pb, 2 * cb), pb.shape[1], tb, nb, float(mb)
-        f.Cn, f.G, f.eps = norm.Cn, norm.G, float(norm.eps)
-        return f, scale, shift
-
     def launch(self, partial, tpb, B):
-        """The fold as a launch of its own (pdr_gn_fold)."""
+        """pdr_gn_fold over this request's statistics -> (scale, shift)."""
         parts = [(partial, self.col0, self.C0, tpb, self.mult0)] + ([self.second] if self.second else [])
         return self.norm.fold(parts, B, self.C, self.n)
 
@@ -407,8 +380,8 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
     """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch).
     extra_rows: zero rows appended to Y (the zero row of a gathered table); out = (tensor, col0): write into
     columns [col0, col0 + ldy') of an existing (P, ld) tensor instead of allocating.
-    fold: a FoldReq -- returns (Y, partial, tiles_per_batch, (scale, shift)) with the GroupNorm fold of this layer's
-    statistics, computed by the layer's own launch where a kernel with a fold tail takes it, else by pdr_gn_fold."""
+    fold: a FoldReq -- returns (Y, partial, tiles_per_batch, (scale, shift)): the GroupNorm fold (pdr_gn_fold) of this
+    layer's statistics is launched right behind it."""
     lib = _lib.load()
     assert act.C == conv.Cin, (act.C, conv.Cin)
     ldy = _ldy(conv.Cout)
@@ -428,16 +401,7 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
     li = act.struct()
     rc0 = conv.Cout if relu_col0 is None else relu_col0
-    folded = None
     done = _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, rc0)
-    if not done and fold is not None and fold.in_launch(act.B, tpb):
-        f, scale, shift = fold.struct(act.B, Y.device)
-        rc = lib.pdr_fused_layer_fold(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
-                                      conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, partial.data_ptr(), rc0,
-                                      ctypes.byref(f), _stream())
-        if rc != _lib.PDR_EUNSUPPORTED:
-            _lib.check(rc, "fused_layer_fold")
-            done, folded = True, (scale, shift)
     if not done:
         rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
                                  conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
@@ -459,9 +423,7 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
         _lib.check(rc, "fused_layer")
     if fold is None:
         return Y, partial, tpb
-    if folded is None:
-        folded = fold.launch(partial, tpb, act.B)
-    return Y, partial, tpb, folded
+    return Y, partial, tpb, fold.launch(partial, tpb, act.B)
 
 
 def materialize(act):
@@ -479,13 +441,6 @@ class Norm:
         gn = mod.group_norm if isinstance(mod, MyGroupNorm) else mod
         self.G, self.Cn, self.eps = gn.num_groups, gn.num_channels, gn.eps
         self.gamma, self.beta = gn.weight.detach().contiguous(), gn.bias.detach().contiguous()
-
-    def tickets(self, B):
-        """Per-batch-element completion counters of this GroupNorm's in-launch fold (zero between launches)."""
-        t = self.__dict__.setdefault("_tickets", {})
-        if B not in t:
-            t[B] = torch.zeros((B,), dtype=torch.int32, device=self.gamma.device)
-        return t[B]
 
     def fold(self, parts, B, C, n):
         """parts: [(partial, col0, ncols, tiles_per_batch, mult)] (one or two) covering C channels in order.
@@ -621,6 +576,8 @@ class FusedMlp:
         first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
         part, tpb = part1, tpb1
         cur = first.attach(Act([first.seg(0, self.C1)], P, B, rpb))
+        if callable(folded):
+            folded = folded()
         for i, norm in enumerate(self.norms):
             C = cur.C
             scale, shift = folded if folded is not None else norm.fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
@@ -779,7 +736,7 @@ class SplitFirstConv:
         balls).  Depends on the SOURCE cloud only, so callers whose source is static across reverse steps (the
         feature-transfer blocks read the retained condition features) compute it once per batch."""
         B, n, Cs = src_feats_cl.shape
-        u_in = Act([(xyz4(src_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
+        u_in = Act(feature_segments(src_feats_cl) + [(xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
         # the table lives in a buffer owned by this block (one per shape), zeroed ONCE: the GEMM rewrites rows
         # [0, B n) every call and nothing ever writes the trailing zero row, so no fill launch per step
         key = (B * n + 1, _ldy(self.U.Cout))
@@ -804,7 +761,7 @@ class SplitFirstConv:
                  virtual=False, res=None, U=None, V2=None, fold=None):
         """-> (Y1, partial, tiles_per_batch, folded).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
         consumers read as a gathered source (only the GroupNorm moments are computed here).  fold: FoldReq of the
-        GroupNorm behind this conv; folded = its (scale, shift) when the launch carried it, else None."""
+        GroupNorm behind this conv; folded = a thunk launching that fold -> (scale, shift), None without request."""
         lib = _lib.load()
         B, n, Cs = src_feats_cl.shape
         m = query_xyz.shape[1]
@@ -824,24 +781,19 @@ class SplitFirstConv:
         partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
         cptr = counts.data_ptr() if has_v0 else None
 
-        folded = []
-
         def gather_add(y, ldy, ycol0, ycols):
-            fptr = None
-            if fold is not None and fold.in_launch(B, tpb):
-                f, scale, shift = fold.struct(B, U.device)
-                fptr = ctypes.byref(f)
-                folded.append((scale, shift))
-            _lib.check(lib.pdr_gather_add_fold(
+            _lib.check(lib.pdr_gather_add(
                 U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
                 s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
                 s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
-                B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, fptr, _stream()),
-                "gather_add")
+                B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, _stream()), "gather_add")
+
+        # (a thunk: the fold is launched by whoever consumes it, i.e. on the stream that runs the rest of the MLP)
+        folded = (lambda: fold.launch(partial, tpb, B)) if fold is not None else None
 
         if not virtual:
             gather_add(Y.data_ptr(), ld, 0, -1)
-            return Y, partial, tpb, (folded[0] if folded else None)
+            return Y, partial, tpb, folded
         # virtual: GroupNorm moments of every column, but only the residual columns (a row-wise add in their
         # consumer, which stays a plain read) are written -- one pass
         Yres = None
@@ -869,7 +821,7 @@ class SplitFirstConv:
                          nsrc=n, zrow=B * n, Yres=Yres, res_col0=res[0] if res else 0,
                          res_cols=res[1] if res else 0, s1=s1, s2=s2, r1=self.r1 if s1 is not None else None,
                          r2=self.r2 if s1 is not None else None, materialise=materialise)
-        return first, partial, tpb, (folded[0] if folded else None)
+        return first, partial, tpb, folded
 
 
 def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with_centre):
@@ -884,7 +836,40 @@ def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with
     return out, Cout
 
 
+class Cat:
+    """[a | b] along the channel axis of two (B, n, C) channel-last tensors, NOT materialised: the layer kernels
+    read a concatenation as separate input segments and pdr_gather_rows2 gathers its rows directly, so the
+    `torch.cat` launches of the reference composition (8 per step) disappear.  dense() builds it where a consumer
+    needs one tensor."""
+
+    def __init__(self, a, b):
+        assert a.shape[:2] == b.shape[:2]
+        self.parts = (a, b)
+        self.shape = (a.shape[0], a.shape[1], a.shape[2] + b.shape[2])
+        self.device = a.device
+        self._dense = None
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = torch.cat(self.parts, dim=2)
+        return self._dense
+
+
+def feature_segments(feats_cl):
+    """Input segments (tensor, offset, C, ld, row_div) of a (B, n, C) feature tensor or a Cat of two."""
+    parts = feats_cl.parts if isinstance(feats_cl, Cat) else (feats_cl,)
+    return [(xyz4(t), 0, t.shape[2], _pad4(t.shape[2]), 1) for t in parts]
+
+
 def gather_rows(src_cl, idx):
+    if isinstance(src_cl, Cat):
+        a, b = src_cl.parts
+        B, n, C = src_cl.shape
+        m = idx.shape[1]
+        out = torch.empty((B, m, C), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().pdr_gather_rows2(a.data_ptr(), a.shape[2], b.data_ptr(), b.shape[2], idx.data_ptr(), B, n,
+                                                m, out.data_ptr(), _stream()), "gather_rows2")
+        return out
     B, n, C = src_cl.shape
     m = idx.shape[1]
     out = torch.empty((B, m, C), dtype=torch.float32, device=src_cl.device)
@@ -949,7 +934,8 @@ class FusedGroupedBlock:
                                     U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K))
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank, folded=folded)
         else:
-            G, Cg = group_build(src_feats_cl, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
+            dense_feats = src_feats_cl.dense() if isinstance(src_feats_cl, Cat) else src_feats_cl
+            G, Cg = group_build(dense_feats, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
                                 self.with_centre)
             h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K, C=Cg), bank)
         return dict(h=h, Y1=Y1, part1=part1, tpb1=tpb1, counts=counts, B=B, m=m, K=K,
@@ -1028,7 +1014,8 @@ class FusedKnnFP:
         else:
             G = torch.empty((B * n * K, _pad4(C + 11)), dtype=torch.float32, device=unknown.device)
             idx64 = idx.long()
-            _lib.check(lib.pdr_knn_build(known_feats_cl.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
+            known_dense = known_feats_cl.dense() if isinstance(known_feats_cl, Cat) else known_feats_cl
+            _lib.check(lib.pdr_knn_build(known_dense.data_ptr(), C, unknown.data_ptr(), known.data_ptr(),
                                          idx64.data_ptr(), d2.data_ptr(), B, n, n2, K, G.data_ptr(), G.shape[1],
                                          _stream()), "knn_build")
             h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
@@ -1166,9 +1153,15 @@ class FusedCloudConditionNet:
             net.decoder_cond_features is None or net.global_feature is None
         if fresh:
             if not FUSE_CONDITION_BRANCH:
-                # first step of a batch (condition branch not retained yet): reference-layout path
-                return net(pointcloud, condition, ts=ts, label=label,
-                           use_retained_condition_feature=use_retained_condition_feature)
+                # first step of a batch (condition branch not retained yet): reference-layout path.  This call does
+                # not pass through _embeddings, so the class-embedding rows of the blocks are refreshed HERE: a
+                # captured step (which contains no class-embedding GEMM) of a later batch would otherwise keep
+                # reading the rows of the batch the graph was captured on
+                out = net(pointcloud, condition, ts=ts, label=label,
+                          use_retained_condition_feature=use_retained_condition_feature)
+                if use_retained_condition_feature and label is not None:
+                    self._refresh_class_embedding(label)
+                return out
         saved = _PRECISION[0]
         _PRECISION[0] = self.precision
         saved_par = _PAR["stream"]
@@ -1194,14 +1187,19 @@ class FusedCloudConditionNet:
                 t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
                 t_emb = net.activation(net.fc_t2(t_emb))
                 bank.evaluate_kind("t", t_emb)
-        # (the key holds the tensor itself: while it is referenced here its address cannot be recycled)
-        key = (label, label._version)
         if self._label_key is None or self._label_key[0] is not label or self._label_key[1] != label._version \
                 or "c2" not in bank.out:
-            bank.evaluate_kind("c2", net.class_emb(label), static=True)
-            self._label_key = key
+            self._refresh_class_embedding(label)
         if "c" not in bank.out:
             bank.evaluate_kind("c", net.global_feature, static=True)
+
+    def _refresh_class_embedding(self, label):
+        """fc_second_condition(class_emb(label)) of every block, IN PLACE (a captured graph keeps its address);
+        remembered by label identity + version."""
+        with torch.no_grad():
+            self.bank.evaluate_kind("c2", self.net.class_emb(label), static=True)
+        # (the key holds the tensor itself: while it is referenced here its address cannot be recycled)
+        self._label_key = (label, label._version)
 
     def _embed_linear_chain(self, ts):
         """calc_t_emb -> fc_t1 -> swish -> fc_t2 -> swish -> every block's fc (pointnet2_with_pcld_condition.py
@@ -1283,23 +1281,15 @@ class FusedCloudConditionNet:
         def fm_key(i, blk):
             return (i % (nlev + 1), blk.radius, blk.nsample)
 
-        first_main = FIRST_BALL_MAIN and LEVEL_EVENTS and not early and AHEAD_LEVEL > nlev
         ev_first = None
-        if first_main:
-            # (embeddings first: three small launches during which the FPS kernel of the geometry stream takes its
-            # 32 workgroup slots; issued behind the ball query it waited for that kernel's 1000+ workgroups to drain)
-            self._embeddings(ts, label)
-            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
-            mark("main:first_ball_query_done")
         with torch.cuda.stream(side):
             mark("side:begin")
-            if not first_main:
-                fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
-                if AHEAD_LEVEL == 0:
-                    xyz4(xyz)
-                mark("side:first_ball_query_done")
-                ev_first = torch.cuda.Event()
-                ev_first.record(side)
+            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
+            if AHEAD_LEVEL == 0:
+                xyz4(xyz)
+            mark("side:first_ball_query_done")
+            ev_first = torch.cuda.Event()
+            ev_first.record(side)
             # Level by level, each with its own events: SA block i starts as soon as ITS sampling / grouping is
             # known, the feature-transfer block of level i + 1 as soon as its ball query is.  (One event after the
             # whole chain made the main stream sit idle from the end of the first feature-transfer block, 0.85 ms
@@ -1357,7 +1347,9 @@ class FusedCloudConditionNet:
             ev_knn.record(side)
 
         # ---- embeddings (A/B: PDR_EARLY_EMBED=0 issues them here, beside the running geometry stream)
-        if not first_main and not early:
+        # (measured and dropped in round 3: the first ball query on the main stream with the FPS chain opening the
+        # geometry stream -- 8.81 / 8.79 / 8.82 vs 8.78 / 8.80 / 8.83 ms per step, no difference)
+        if not early:
             self._embeddings(ts, label)
         mark("main:embeddings_done")
 
@@ -1408,7 +1400,7 @@ class FusedCloudConditionNet:
                 if ev_tables is not None:
                     main.wait_event(ev_tables)
                 mark("main:after_wait_encoder_geometry")
-            sa_in = torch.cat([mapped, l_feat[i]], dim=2)
+            sa_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
             centre = gather_rows(sa_in, sels[i])
             l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i],
                              V2=tables.get(id(sa))))
@@ -1416,7 +1408,7 @@ class FusedCloudConditionNet:
         main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
             mapped = transfer(self.dec_map[i], i % (nlev + 1), dec_cl, l_feat[i], V2=tables.get(id(self.dec_map[i])))
-            fp_in = torch.cat([mapped, l_feat[i]], dim=2)
+            fp_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
             mark("main:dec_map%d_done" % (i % (nlev + 1)))
             l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i],
                                        V2=tables.get(id(self.fp[i])))
@@ -1440,6 +1432,7 @@ class FusedCloudConditionNet:
     def reset_cond_features(self):
         self.net.reset_cond_features()
         self._synced = False
+        self._label_key = None          # a new batch: the class embedding rows are refreshed on first use
 
     def parameters(self):
         return self.net.parameters()

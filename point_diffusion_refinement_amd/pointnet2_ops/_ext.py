@@ -219,8 +219,19 @@ def knn_group(x, y, K):
     _req(x, "x", torch.float32)
     _req(y, "y", torch.float32)
     _same_device(x, y)
+    if x.dim() != 3 or y.dim() != 3 or x.shape[2] != 3 or y.shape[2] != 3 or x.shape[0] != y.shape[0]:
+        raise RuntimeError("knn_group: x (B,n1,3) and y (B,n2,3) with equal batch size required, got %s and %s"
+                           % (tuple(x.shape), tuple(y.shape)))
     B, n1, _ = x.shape
     n2 = y.shape[1]
+    K = int(K)
+    if K > min(n2, 16):
+        # outside pdr_knn_group's contract (no padding slots, K <= 16): knn_points pads like pytorch3d (idx -1,
+        # distance 0); weights as group_knn computes them from the squared distances
+        d, i, _ = knn_points(x, y, K)
+        w = 1.0 / (d + 1e-8)
+        w = w / w.sum(dim=2, keepdim=True)
+        return d, i.clamp(min=0).to(torch.int32), w
     d = torch.empty((B, n1, K), dtype=torch.float32, device=x.device)
     w = torch.empty((B, n1, K), dtype=torch.float32, device=x.device)
     i = torch.empty((B, n1, K), dtype=torch.int32, device=x.device)

@@ -123,53 +123,6 @@ def test_native_step_embedding_chain_equals_the_torch_chain(cuda, monkeypatch):
     net.global_feature = None
 
 
-@pytest.mark.parametrize("B,rpb,Cin,Cout,Cn", [(3, 256, 40, 64, 64), (32, 512, 96, 512, 512), (5, 2048, 64, 79, 64),
-                                               (64, 128, 32, 96, 96), (2, 8192, 32, 128, 128)])
-def test_in_launch_groupnorm_fold_equals_the_separate_fold(cuda, B, rpb, Cin, Cout, Cn, monkeypatch):
-    """pdr_fused_layer_fold (csrc/gn_tail_fold.h): the workgroup completing a batch element folds it.  Same scale /
-    shift as pdr_fused_layer + pdr_gn_fold (double sums in a different fixed order: 1e-6), tickets left at zero, a
-    second launch on the same tickets gives the same bits; also the two-source form (q half counted K times + key
-    half from another launch) of the attention score GroupNorm, and MyGroupNorm's pass-through channels."""
-    from point_diffusion_refinement_amd.pointnet2_ops.attention import MyGroupNorm
-    g = torch.Generator().manual_seed(B + rpb + Cout)
-    x = (torch.randn(B * rpb, Cin, generator=g) * 1.5 + 0.3).to(cuda)
-    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
-    conv = _conv(W, torch.randn(Cout, generator=g).to(cuda))
-    norm = FN.Norm(fill_deterministic(MyGroupNorm(32, Cout), 3).to(cuda))
-    assert norm.Cn == Cn
-    act = FN.plain(x, B, rpb)
-    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 0)
-    Y0, p0, tpb, (s0, t0) = FN.run_layer(act, conv, fold=FN.FoldReq(norm, Cout, rpb))
-    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 1 << 20)
-    plan = (ctypes.c_int * 7)()
-    li = act.struct()
-    _lib.check(_lib.load().pdr_fused_layer_plan(ctypes.byref(li), act.P, Cin, conv.Wt.data_ptr(), conv.ldw, Cout, None,
-                                                FN._ldy(Cout), plan), "plan")
-    for it in range(2):
-        Y1, p1, _, (s1, t1) = FN.run_layer(act, conv, fold=FN.FoldReq(norm, Cout, rpb))
-        assert torch.equal(Y0, Y1) and torch.equal(p0, p1)
-        np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6, atol=1e-7)
-        np.testing.assert_allclose(t1.cpu().numpy(), t0.cpu().numpy(), rtol=2e-6, atol=2e-6)
-        if plan[0]:                                                       # wave-specialised kernel: fold in the launch
-            assert int(norm.tickets(B).abs().sum()) == 0
-        if it == 0:
-            first = (s1.clone(), t1.clone())
-    assert torch.equal(first[0], s1) and torch.equal(first[1], t1)
-    # two sources: [this layer's first 32 columns counted K = 8 times | columns 8.. of another launch's moments]
-    K, C2 = 8, 32
-    x2 = torch.randn(B * rpb * K, 16, generator=g).to(cuda)
-    conv2 = _conv((torch.randn(C2 + 8, 16, generator=g) / 4).to(cuda), torch.zeros(C2 + 8, device=cuda))
-    _, p2, tpb2 = FN.run_layer(FN.plain(x2, B, rpb * K), conv2, stats=True)
-    n1 = FN.Norm(fill_deterministic(MyGroupNorm(32, 32 + C2), 4).to(cuda))
-    req = lambda: FN.FoldReq(n1, 32, rpb * K, mult0=float(K), second=(p2, 8, C2, tpb2, 1.0))
-    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 0)
-    _, _, _, (sa, ta) = FN.run_layer(act, conv, fold=req())
-    monkeypatch.setattr(FN, "FOLD_TAIL_KB", 1 << 20)
-    _, _, _, (sb, tb) = FN.run_layer(act, conv, fold=req())
-    np.testing.assert_allclose(sb.cpu().numpy(), sa.cpu().numpy(), rtol=2e-6, atol=1e-7)
-    np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), rtol=2e-6, atol=2e-6)
-
-
 def test_groupnorm_fold_matches_torch_groupnorm(cuda):
     g = torch.Generator().manual_seed(3)
     B, rpb, C = 3, 256, 79                                               # MyGroupNorm(32, 79): 64 normalised + 15 pass-through
@@ -275,6 +228,29 @@ def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
     torch.manual_seed(78)
     b = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=False).sample((2, 2048, 3), cond2, label2)
     assert ((a - b).abs() / (b.abs() + 1.0)).max() < 1e-5         # same kernels, same inputs
+
+
+@pytest.mark.parametrize("fuse_branch", [False, True])
+def test_second_batch_with_other_labels_through_the_captured_graph(cuda, fuse_branch, monkeypatch):
+    """The class-embedding rows of the blocks live in a static buffer that a captured step only READS: a second batch
+    with DIFFERENT labels must refresh them before its replays -- also when the first step of a batch takes the
+    layer-by-layer path (PDR_FUSE_CONDITION_BRANCH=0) and never reaches the embedding bank."""
+    monkeypatch.setattr(FN, "FUSE_CONDITION_BRANCH", fuse_branch)
+    net, fused = _pair(small_fused_config(), 23, cuda)
+    dh = util.calc_diffusion_hyperparams(5, 1e-4, 0.02)
+    g = torch.Generator().manual_seed(11)
+    cond = torch.cat([torch.rand(2, 256, 3, generator=g) * 2 - 1, torch.ones(2, 256, 1)], 2).to(cuda)
+    graphed = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True)
+    outs = []
+    for labels in ([1, 5], [9, 2]):
+        label = torch.tensor(labels, device=cuda)
+        torch.manual_seed(31)
+        a = graphed.sample((2, 128, 3), cond, label)
+        torch.manual_seed(31)
+        b = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=False).sample((2, 128, 3), cond, label)
+        assert ((a - b).abs() / (b.abs() + 1.0)).max() < 1e-5, labels          # same kernels, same inputs
+        outs.append(a)
+    assert (outs[0] - outs[1]).abs().max() > 1e-4                              # the label does matter
 
 
 @pytest.mark.parametrize("P,Cin,Cout,rpb", [(512, 13, 96, 256), (1024, 331, 587, 512), (256, 64, 32, 256),

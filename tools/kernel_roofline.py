@@ -94,12 +94,40 @@ def _work(name, args, lib):
         B, npoint, K, D = args[8], args[9], args[10], args[11]
         P = B * npoint * K
         return "attention_pool_*", 6.0 * P * D, 8.0 * P * D + 4.0 * B * npoint * D
+    if name == "pdr_gn_fold":
+        # per-tile partial moments in, (B, C) scale / shift out; no arithmetic worth counting: a latency-bound launch
+        tpb0, C0, tpb1, C1, B = args[2], args[3], args[7], args[8], args[10]
+        C = C0 + (C1 if args[5] else 0)
+        return "gn_fold_kernel", 0.0, 8.0 * B * (tpb0 * C0 + (tpb1 * C1 if args[5] else 0)) + 8.0 * B * C
+    if name == "pdr_furthest_point_sampling":
+        # m - 1 rounds of N distance updates (8 flops per pair); 12 N + 4 m bytes per cloud.  VALU-side
+        # work on 32 of 256 CUs behind a chain of m - 1 dependent rounds: the floor is the round latency, not a roof
+        B, N, m = args[1], args[2], args[3]
+        return "fps_*_kernel N=%d m=%d" % (N, m), 8.0 * B * N * max(m - 1, 0), B * (12.0 * N + 4.0 * m), "valu"
+    if name == "pdr_ball_query":
+        B, n, m, ns = args[2], args[3], args[4], args[6]
+        return "ball_query_kernel", 8.0 * B * n * m, B * (12.0 * (n + m) + 4.0 * m * ns + 4.0 * m), "valu"
+    if name in ("pdr_knn_group", "pdr_knn_points"):
+        B, n1, n2, K = args[2], args[3], args[4], args[5]
+        return "knn (K=%d)" % K, 8.0 * B * n1 * n2, B * (12.0 * (n1 + n2) + 12.0 * n1 * K), "valu"
+    if name == "pdr_embed_linear":
+        B, K, N = args[8], args[9], args[10]
+        return "embed_linear_kernel", 2.0 * B * K * N, 4.0 * (K * N + B * K + B * N)
+    if name == "pdr_reverse_step":
+        return "reverse_step_kernel", 0.0, 36.0 * args[12]
+    if name == "pdr_pad_rows":
+        return "pad_rows_kernel", 0.0, 4.0 * args[1] * (args[2] + args[4])
+    if name == "pdr_gather_rows":
+        B, C, m = args[2], args[4], args[5]
+        return "gather_rows_cl_kernel", 0.0, B * m * (8.0 * C + 4.0)
+    if name == "pdr_apply_act":
+        return "apply_act_kernel", 0.0, 8.0 * args[1] * args[2]
     return name.replace("pdr_", "") + " (C ABI)", 0.0, 0.0
 
 
 _TIMED = ("pdr_fused_layer", "pdr_fused_layer_bf16x3", "pdr_fused_layer_pool", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
           "pdr_furthest_point_sampling", "pdr_ball_query", "pdr_knn_points", "pdr_group_build", "pdr_knn_build",
-          "pdr_knn_weights", "pdr_pad_rows")
+          "pdr_knn_weights", "pdr_pad_rows", "pdr_knn_group", "pdr_embed_linear", "pdr_reverse_step")
 
 
 def latest_traffic_file():
@@ -146,7 +174,8 @@ def step_kernel_table(sampler, reps=3, overlapped=False):
                 e0.record()
                 rc = fn(*args)
                 e1.record()
-                records.append((e0, e1) + _work(name, args, lib))
+                w = _work(name, args, lib)
+                records.append((e0, e1) + tuple(w[:3]) + (w[3] if len(w) > 3 else "mfma",))
                 return rc
             return timed
         setattr(lib, name, make(name, fn))
@@ -161,8 +190,8 @@ def step_kernel_table(sampler, reps=3, overlapped=False):
         for name, fn in installed:
             setattr(lib, name, fn)        # back to the CDLL's own (typed) function object
     table = collections.OrderedDict()
-    for e0, e1, sym, fl, by in records:
-        row = table.setdefault(sym, [0, 0.0, 0.0, 0.0])
+    for e0, e1, sym, fl, by, kind in records:
+        row = table.setdefault(sym, [0, 0.0, 0.0, 0.0, kind])
         row[0] += 1
         row[1] += e0.elapsed_time(e1)
         row[2] += fl
@@ -170,7 +199,7 @@ def step_kernel_table(sampler, reps=3, overlapped=False):
     return table
 
 
-def _roof(flops, byt, ms, symbol):
+def _roof(flops, byt, ms, symbol, kind="mfma"):
     # split mode: three bf16 MFMAs per algorithmic product -> a third of the dense bf16 peak
     args = symbol[symbol.find("<") + 1:symbol.rfind(">")].split(", ") if "<" in symbol else []
     split = symbol.startswith("fused_layer_ws_kernel") and len(args) >= 8 and args[7] == "true"
@@ -179,7 +208,8 @@ def _roof(flops, byt, ms, symbol):
     t_hbm = byt / (HBM_PEAK_GBS * 1e9)
     if t_mfma >= t_hbm and flops > 0:
         ach = flops / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+        # kind "valu": fp32 vector work (157.3 TF is the fp32 VALU peak as well as the fp32 MFMA peak)
+        return {"bound": kind, "achieved": round(ach, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak_tf, 4)}
     ach = byt / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -189,12 +219,12 @@ def _roof(flops, byt, ms, symbol):
 def dominant_kernel_roofline(sampler, reps=3):
     table = step_kernel_table(sampler, reps)
     ranked = sorted(table.items(), key=lambda kv: -kv[1][1])
-    sym, (n, ms, fl, by) = ranked[0]
-    out = _roof(fl, by, ms, sym)
+    sym, (n, ms, fl, by, kind) = ranked[0]
+    out = _roof(fl, by, ms, sym, kind)
     try:
         ovl = step_kernel_table(sampler, 2, overlapped=True).get(sym)
         if ovl:
-            r = _roof(ovl[2], ovl[3], ovl[1], sym)
+            r = _roof(ovl[2], ovl[3], ovl[1], sym, kind)
             out["in_step_two_streams"] = {"avg_launch_us": round(ovl[1] / ovl[0] * 1e3, 2), "achieved": r["achieved"],
                                           "frac": r["frac"],
                                           "note": "same launches while the other half of each block runs beside them "
@@ -213,6 +243,7 @@ def dominant_kernel_roofline(sampler, reps=3):
         "note": "dominant = largest HIP-event time among the C-ABI launches of %d eager steps with the blocks' halves "
                 "serialised on one stream (a kernel alone on the chip; agrees with profiles/*_bench_kernel_stats_serial"
                 ".csv); events include ~3 us of eager launch latency per call" % reps,
-        "next": [{"kernel": s, "share": round(v[1] / total, 4), **_roof(v[2], v[3], v[1], s)} for s, v in ranked[1:6]],
+        "next": [{"kernel": s, "share": round(v[1] / total, 4), "avg_launch_us": round(v[1] / v[0] * 1e3, 2),
+                  **_roof(v[2], v[3], v[1], s, v[4])} for s, v in ranked[1:6]],
     })
     return out
