@@ -252,6 +252,8 @@ bool launch_knn_wave(const float* x, const float* y, int B, int n1, int n2, int 
     return !(e && e[0] == '0');
   }();
   if (!on || K > 8 || n2 < 64 || n2 > 1024) return false;
+  // queries per wave: amortise the register fill of the cloud while the launch keeps >= 1024 workgroups (measured at
+  // 2048 x 1024, B = 32: 4 / 8 / 16 queries per wave 60.6 / 60.1 / 60.3 us, 32: 88.6 us)
   int qpw = 16;
   while (qpw > 1 && static_cast<long long>(B) * ((n1 + 4 * qpw - 1) / (4 * qpw)) < 1024) qpw >>= 1;
   const dim3 grid((n1 + 4 * qpw - 1) / (4 * qpw), B);

@@ -148,6 +148,23 @@ def network_ddpm():
     save("network_ddpm.npz", eps_first=first, eps_cached=cached)
 
 
+def sampling_ddpm():
+    """The reference's own `sampling` loop (util.py:184-255) on the shipped DDPM architecture at FULL size (B = 2,
+    N = 2048, 3072-point condition), T = 6, CPU noise stream of seed 321: the denoised clouds AND the x_t handed to
+    every network call (for the discrete-decision replay of tests/parity.py)."""
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    from util import calc_diffusion_hyperparams, sampling
+    from tests.parity import InputRecorder
+    x, cond, _, label = I.ddpm_inputs(B=2)
+    net = fill_deterministic(PointNet2CloudCondition(R.load_config()['pointnet_config']), 31).eval()
+    dh = calc_diffusion_hyperparams(6, 1e-4, 0.02)
+    rec = InputRecorder(net)
+    torch.manual_seed(321)
+    out = quiet(sampling, net, tuple(x.shape), dh, label=label, verbose=False, condition=cond)
+    rec.close()
+    save("sampling_ddpm.npz", out=out, xs=torch.stack(rec.xs))
+
+
 def schedules():
     from util import calc_diffusion_hyperparams
     import util_fastdpmv2 as F
@@ -246,6 +263,7 @@ if __name__ == "__main__":
     layers()
     network()
     network_ddpm()
+    sampling_ddpm()
     schedules()
     metrics()
     mirror()

@@ -215,6 +215,62 @@ def test_full_ddpm_config_forward_matches_reference(be):
                      g["eps_cached"], "ddpm_full_fused:eps_cached", x * 0.9)
 
 
+def test_full_ddpm_config_sampling_loop_matches_reference(be):
+    """The reference's `sampling` loop at FULL size (shipped DDPM architecture, B = 2, N = 2048, 3072-point condition,
+    T = 6, CPU noise stream; tests/golden/make_golden.py sampling_ddpm() from the imported reference).  cpu-oracle: the
+    product loop over the oracle ops.  hip: the layer-by-layer loop, the fused eager loop and the fused hipGraph loop
+    -- denoised coordinates of every cloud without a flipped discrete decision within north_star's 1e-4 of the
+    reference (decisions recomputed by the CPU oracle from the x_t of every network call of both trajectories)."""
+    from point_diffusion_refinement_amd.pointnet2.configs import ddpm_pointnet_config
+    g = gold("sampling_ddpm.npz")
+    x, cond, _, label = be.to(*I.ddpm_inputs(B=2))
+    net = fill_deterministic(PointNet2CloudCondition(ddpm_pointnet_config()), 31).eval().to(be.device)
+    dh = util.calc_diffusion_hyperparams(6, 1e-4, 0.02)
+    ref_xs = [torch.from_numpy(a) for a in g["xs"]]
+    rec = parity.InputRecorder(net)
+    with torch.no_grad(), be.ops():
+        torch.manual_seed(321)
+        out = _quiet(util.sampling, net, tuple(x.shape), dh, label=label, verbose=False, condition=cond)
+    rec.close()
+    if be.kind == "cpu-oracle":
+        return be.close(out, g["out"], "ddpm_full:sampling_T6", 50)
+    assert torch.equal(rec.xs[0], ref_xs[0])                               # the same x_T: identical CPU noise stream
+    cfg = ddpm_pointnet_config()
+
+    def judge(name, got, xs):
+        """At this size a flipped decision is the RULE, not the exception: 1023 + 255 + 63 + 15 greedy FPS rounds over
+        2048 points per call, each an arg-max whose runner-up is typically 5e-4 behind -- a 1e-7 difference in x_t
+        flips a pick in roughly one of five cloud-steps (measured: both clouds within 6 steps).  What CAN be held to
+        north_star's 1e-4 is every x_t a cloud hands to the network up to and including the call in which its first
+        decision flips (those inputs are still pre-flip values), and the final cloud of the clouds that never flip;
+        after a flip the cloud is a different valid sample: loose sanity bound + count, recorded."""
+        flipped, first = parity.flipped_clouds(cfg, xs, ref_xs, cond)
+        B = len(flipped)
+        last_ok = [first[b][0] if flipped[b] else len(xs) - 1 for b in range(B)]
+        for k in range(1, len(xs)):
+            live = np.array([k <= last_ok[b] for b in range(B)])
+            if live.any():
+                be._check("%s:x_t_call%d" % (name, k), xs[k], ref_xs[k], be.COORD, clouds=live)
+        extra = {"network_calls": len(xs), "flipped_clouds": int(flipped.sum()),
+                 "first_flip": [None if f is None else list(f) for f in first]}
+        be._check(name + ":denoised_coordinates", got, g["out"], be.COORD, clouds=~flipped, extra=extra)
+        if flipped.any():
+            be._check(name + ":flipped_clouds", got, g["out"], 1e-3, clouds=flipped)    # measured 1.4e-6
+    judge("ddpm_full:sampling_T6:layer_by_layer", out, rec.xs)
+    from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
+    from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedReverseSampler
+    fused = FusedCloudConditionNet(net)
+    for use_graph in (False, True):
+        sampler = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=use_graph)
+        torch.manual_seed(321)
+        sampler.begin(tuple(x.shape), cond, label)                         # draws x_T, runs the first (uncached) step
+        xs = [ref_xs[0]]
+        while sampler.remaining > 0:
+            xs.append(sampler._x.detach().cpu().clone())
+            sampler.advance(1)
+        judge("ddpm_full:sampling_T6:fused_%s" % ("graph" if use_graph else "eager"), sampler.finish(), xs)
+
+
 def test_network_forward_caching_and_samplers(be):
     g = gold("network_tiny.npz")
     x, cond, ts, label = be.to(*I.network_inputs())

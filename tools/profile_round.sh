@@ -8,7 +8,7 @@
 #   3. tools/op_roofline.py: FPS / ball_query / kNN / Chamfer / EMD at the BASELINE sizes, HIP-event timed
 #   4. tools/profile_summary.py -> <tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json, <tag>_mfma_util.json,
 #      <tag>_roofline.json
-TAG=${1:-r2}
+TAG=${1:-r3}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -34,6 +34,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 tail -1 $OUT/${TAG}_pmc.SQ.log | cut -c1-120
 cd $REPO
 python tools/op_roofline.py > $OUT/${TAG}_op_roofline.json 2> $OUT/${TAG}_op_roofline.err
+# time stamps inside an UNTRACED graph replay (pdr_mark_time kernels captured with the step): block-level and, in the
+# second file, inside every block
+python -m tools.lab.step_markers $OUT/${TAG}_timeline_markers.json > $OUT/${TAG}_timeline_markers.txt 2>&1
+MARK_DETAIL=1 python -m tools.lab.step_markers $OUT/${TAG}_timeline_markers_detail.json > /dev/null 2>&1
 python tools/profile_summary.py $OUT $TAG
 # raw counter dumps are large: keep only the summaries
 rm -rf $OUT/${TAG}_pmc $OUT/${TAG}_stats

@@ -53,7 +53,7 @@ def counters(path, wanted):
 def timeline(out, tag):
     """<tag>_timeline.json: every kernel of ONE replayed reverse step (the last complete one of the --stats pass):
     [short name, start us relative to the step's first kernel, duration us, queue id].  A step ends with the
-    reverse_update kernel; its kernels may run on several hardware queues (geometry side stream)."""
+    reverse_step (round <= 2: reverse_update) kernel; its kernels may run on several hardware queues (geometry side stream)."""
     src = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_trace.csv"), recursive=True)
     if not src:
         return
@@ -61,7 +61,7 @@ def timeline(out, tag):
     for r in csv.DictReader(open(src[0])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if "reverse_update" in r[2]]
+    ends = [i for i, r in enumerate(rows) if "reverse_update" in r[2] or "reverse_step" in r[2]]
     if len(ends) < 3:
         return
     lo, hi = ends[-2] + 1, ends[-1]
