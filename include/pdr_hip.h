@@ -23,13 +23,16 @@
  *   - return value: PDR_OK (0) or a negative PDR_E* code.  Nothing prints or
  *     calls exit() (contrast cuda_utils.h:30-39).  No hidden allocation, no
  *     device synchronisation, no mutable global state: calls are thread-safe and
- *     capturable into a hipGraph.  The only process-wide inputs are three tuning
+ *     capturable into a hipGraph.  The only process-wide inputs are five tuning
  *     knobs read ONCE from the environment (kernel selection only; results are
- *     identical, for the layer kernels up to fp32 summation order):
+ *     identical, for the layer kernels and the GroupNorm fold up to fp32 / fp64
+ *     summation order):
  *     PDR_FUSED_WS=0 (uniform-wave layer kernels), PDR_NARROW_KC32=0 (256-row
- *     tiles for outputs of <= 64 channels, see pdr_fused_layer_tile_rows) and
+ *     tiles for outputs of <= 64 channels, see pdr_fused_layer_tile_rows),
  *     PDR_FPS_WAVE=0|2 (furthest-point-sampling kernel family, see
- *     pdr_furthest_point_sampling).
+ *     pdr_furthest_point_sampling), PDR_KNN_WAVE=0 (thread-per-query instead of
+ *     wave-per-query kNN for K <= 8) and PDR_GN_FOLD_SMALL=0 (1024-thread
+ *     GroupNorm fold workgroups).
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined
  *     behaviour, as in the reference's kernels).
