@@ -262,11 +262,12 @@ class Conv:
 # off 11.08 / 11.14, blocks of <= 65,536 positions 11.05 / 11.03, <= 1 M positions 10.94 / 10.94, all blocks
 # 10.89 / 10.88 (B = 8: 5.61 -> 5.30 with the deep levels alone): the small launches of one half fill the gaps and
 # tails of the other, also at level 0.  PDR_PAR_DEEP=0 turns it off, PDR_PAR_MAX_ROWS bounds it (A/B).
-# Per-query first-conv tables ([V | V0]: coordinates x static weights) of every block but the first CAN be evaluated
-# on the geometry stream right after the last ball query (~2 small GEMMs + a pad per block leave the main stream).
-# Measured on MI355X (B = 32, same box): 10.85 / 10.91 ms per step vs 10.87 / 10.87 inside the blocks (B = 8: 5.20 vs
-# 5.17) -- no gain once the blocks run their halves on two streams -- so it is OFF; PDR_SIDE_TABLES=1 enables it.
-SIDE_TABLES = __import__("os").environ.get("PDR_SIDE_TABLES", "0") == "1"
+# Per-query first-conv tables ([V | V0]: coordinates x static weights; one thin launch per block) are evaluated on the
+# geometry stream as soon as a level's coordinates exist, ahead of that level's event, instead of at the head of
+# their block on the main stream.  Round 2 (tables after the WHOLE geometry chain, two launches per block): 10.85 /
+# 10.91 vs 10.87 / 10.87 ms, no gain.  Round 3 (per level, merged launch; same box, B = 32): 8.615 / 8.601 / 8.623 vs
+# 8.642 / 8.660 / 8.675 inside the blocks (B = 8: 4.17 vs 4.22) -- on.  PDR_SIDE_TABLES=0: inside the blocks.
+SIDE_TABLES = __import__("os").environ.get("PDR_SIDE_TABLES", "1") == "1"
 _PAR = {"stream": None}
 PAR_DEEP = __import__("os").environ.get("PDR_PAR_DEEP", "1") == "1"
 PAR_MAX_ROWS = int(__import__("os").environ.get("PDR_PAR_MAX_ROWS", str(1 << 40)))
@@ -721,6 +722,14 @@ class SplitFirstConv:
             self.U = _RawConv(torch.cat([W_f, W_rel + W_abs], 0), zb, Cout)
             self.V = _RawConv(W_ctr - W_rel, bias, Cout)
             self.V0 = _RawConv(W_abs + W_ctr, bias, Cout)
+            # [V | V0] as ONE rank-3 product (one thin launch per block instead of two): columns [0, Cout) and
+            # [ld, ld + Cout) of a 2 ld wide table, the padding columns have zero weights
+            ld = _ldy(Cout)
+            wcat = torch.zeros((3, 2 * ld), device=dev)
+            bcat = torch.zeros(2 * ld, device=dev)
+            wcat[:, :first.ldw], wcat[:, ld:ld + first.ldw] = self.V.Wt, self.V0.Wt
+            bcat[:Cout], bcat[ld:ld + Cout] = bias, bias
+            self.VV0 = _RawConv(wcat, bcat, 2 * ld)
             self.r1 = self.r2 = None
         else:
             # (4 floats of slack: consumers read these rows in 16-byte pieces up to a segment's 4-padded width)
@@ -752,9 +761,10 @@ class SplitFirstConv:
         ld = _ldy(self.U.Cout)
         q_in = plain(xyz4(query_xyz).reshape(B * m, 4), B, m, C=3)
         V2 = torch.empty((B * m, 2 * ld if has_v0 else ld), dtype=torch.float32, device=query_xyz.device)
-        run_layer(q_in, self.V, out=(V2, 0))
         if has_v0:
-            run_layer(q_in, self.V0, out=(V2, ld))
+            run_layer(q_in, self.VV0, out=(V2, 0))
+        else:
+            run_layer(q_in, self.V, out=(V2, 0))
         return V2
 
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
@@ -1276,7 +1286,7 @@ class FusedCloudConditionNet:
         xyz4(xyz)
         side.wait_stream(main)
         nlev = len(self.sa)
-        l_xyz, sels, fm_neigh, sa_neigh, knn = [xyz], [], {}, [], {}
+        l_xyz, sels, fm_neigh, sa_neigh, knn, tables = [xyz], [], {}, [], {}, {}
 
         def fm_key(i, blk):
             return (i % (nlev + 1), blk.radius, blk.nsample)
@@ -1287,6 +1297,8 @@ class FusedCloudConditionNet:
             fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
             if AHEAD_LEVEL == 0:
                 xyz4(xyz)
+            if SIDE_TABLES and LEVEL_EVENTS and self.enc_map[0].split is not None:
+                tables[id(self.enc_map[0])] = self.enc_map[0].split.query_tables(xyz, has_v0=True)
             mark("side:first_ball_query_done")
             ev_first = torch.cuda.Event()
             ev_first.record(side)
@@ -1302,6 +1314,8 @@ class FusedCloudConditionNet:
                 sa_neigh.append(sa.neighbours(l_xyz[i], l_xyz[i + 1]))
                 if LEVEL_EVENTS:
                     xyz4(l_xyz[i + 1])          # padded coordinates of the new level: produced before its event
+                    if SIDE_TABLES and sa.split is not None:
+                        tables[id(sa)] = sa.split.query_tables(l_xyz[i + 1], has_v0=False)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     ev_sa.append(ev)
@@ -1309,6 +1323,8 @@ class FusedCloudConditionNet:
                     for blk in ([self.enc_map[lv]] if lv < nlev else []) + [self.dec_map[lv]]:
                         if fm_key(lv, blk) not in fm_neigh:
                             fm_neigh[fm_key(lv, blk)] = blk.neighbours(l_uvw[lv], l_xyz[lv])
+                        if SIDE_TABLES and blk.split is not None:
+                            tables[id(blk)] = blk.split.query_tables(l_xyz[lv], has_v0=True)
                     ev_fm[lv] = torch.cuda.Event()
                     ev_fm[lv].record(side)
             for i in range(nlev + 1):
@@ -1324,8 +1340,16 @@ class FusedCloudConditionNet:
             mark("side:encoder_geometry_done")
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
-            tables, ev_tables = {}, None
-            if SIDE_TABLES and USE_SPLIT_FIRST:
+            ev_tables = None
+            if SIDE_TABLES and USE_SPLIT_FIRST and LEVEL_EVENTS:
+                # per level above; here the rest: the level-0 decoder block and the feature-propagation blocks (used
+                # by the decoder, behind ev_knn)
+                if self.dec_map[0].split is not None:
+                    tables[id(self.dec_map[0])] = self.dec_map[0].split.query_tables(l_xyz[0], has_v0=True)
+                for i in range(-1, -(len(self.fp) + 1), -1):
+                    if self.fp[i].split is not None:
+                        tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
+            elif SIDE_TABLES and USE_SPLIT_FIRST:
                 # (a block's SplitFirstConv exists from its first evaluation on; the eager first step of a batch
                 # therefore computes the tables inline, every captured step here)
                 for i in range(nlev + 1):
@@ -1388,7 +1412,7 @@ class FusedCloudConditionNet:
             if LEVEL_EVENTS and i > 0:
                 main.wait_event(ev_fm[i])
             mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i],
-                              V2=v2_first if i == 0 else tables.get(id(self.enc_map[i])))
+                              V2=v2_first if (i == 0 and v2_first is not None) else tables.get(id(self.enc_map[i])))
             mark("main:enc_map%d_done" % i)
             if LEVEL_EVENTS:
                 main.wait_event(ev_sa[i])
