@@ -38,6 +38,7 @@ class GraphedReverseSampler:
         sig = S.clone()
         sig[0] = 0.0
         self.sigma = sig.to(self.device)
+        self._sigma_raw = S.to(self.device)            # Sigma[step] of the restart option (sigma_0 not zeroed)
         self._graph = None
         self._key = None
 
@@ -91,9 +92,11 @@ class GraphedReverseSampler:
         """Device table of network time inputs indexed by the step counter, or None = float(t) (DDPM)."""
         return None
 
-    def _step(self):
+    def _step(self, keep_slice=None):
+        """One reverse step.  keep_slice: a list -- the step runs in PyTorch ops and appends the cloud BEFORE the noise
+        is added, what util.sampling stores for `return_multiple_t_slices` (util.py:246-248)."""
         t = self._t                                   # (1,) int64 on device, counts down to 0
-        native = self._native()
+        native = self._native() and keep_slice is None
         B = self._x.shape[0]
         # native: the time input of this step was published by the previous step's pdr_reverse_step (or by begin())
         ts = (self._ts if native else self._timestep(t)).expand(B)
@@ -110,8 +113,18 @@ class GraphedReverseSampler:
             self._step_native(eps)
             return
         z = torch.randn_like(self._x) if self.noise == 'device' else self._z
-        self._x.copy_(self._update(self._x, eps, t, z))
+        if keep_slice is not None:
+            if self.UPDATE_MODE != 0:
+                raise NotImplementedError("t-slices exist for the DDPM loop only (util.sampling)")
+            c_eps, sqrt_a, sigma = (tab.index_select(0, t) for tab in self._tables())
+            x = (self._x - c_eps * eps) / sqrt_a
+            keep_slice.append(x.clone())
+            self._x.copy_(x + sigma * z)
+        else:
+            self._x.copy_(self._update(self._x, eps, t, z))
         self._t.sub_(1)
+        if self._x.is_cuda:
+            self._ts.copy_(self._timestep(self._t.clamp(min=0)))   # what pdr_reverse_step publishes on the native path
 
     def _prepare(self, size, condition, label):
         key = (tuple(size), tuple(condition.shape), None if label is None else tuple(label.shape))
@@ -178,7 +191,7 @@ class GraphedReverseSampler:
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
-    def begin(self, size, condition, label=None, x_T=None, start_step=None):
+    def begin(self, size, condition, label=None, x_T=None, start_step=None, keep_slice=None):
         """Load a batch: x_T (drawn like the reference if not given), condition, labels; run the first
         (uncached) reverse step eagerly so the network retains its condition features."""
         self._prepare(size, condition, label)
@@ -195,7 +208,7 @@ class GraphedReverseSampler:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             self._rng.copy_(torch.tensor([seed, 0], dtype=torch.int64))
         self.remaining = t0 + 1
-        self._advance_eager()                          # first step: condition branch runs and is retained
+        self._advance_eager(keep_slice)                # first step: condition branch runs and is retained
         if self._graph is not None:
             self._adopt_cache()
         if hasattr(self.net, "sync_condition"):
@@ -208,9 +221,9 @@ class GraphedReverseSampler:
         elif self.noise == 'cpu':
             self._z.zero_()
 
-    def _advance_eager(self):
+    def _advance_eager(self, keep_slice=None):
         self._draw_cpu_noise()
-        self._step()
+        self._step(keep_slice)
         self.remaining -= 1
 
     @torch.no_grad()
@@ -235,10 +248,37 @@ class GraphedReverseSampler:
         return out
 
     @torch.no_grad()
-    def sample(self, size, condition, label=None, x_T=None):
-        """Equivalent of util.sampling(net, size, dh, label=label, condition=condition)."""
-        self.begin(size, condition, label, x_T)
-        return self.finish()
+    def sample(self, size, condition, label=None, x_T=None, return_multiple_t_slices=False,
+               t_slices=(5, 10, 20, 50, 100, 200, 400, 600, 800), use_a_precomputed_XT=False, step=100, XT=None):
+        """Equivalent of util.sampling(net, size, dh, label=label, condition=condition, ...) incl. its two options
+        (util.py:217-222, 246-248):
+          use_a_precomputed_XT: restart from a stored x^step: x = XT + Sigma[step] z, then steps step-1 ... 0;
+          return_multiple_t_slices: also return {t: cloud after the update of step t, BEFORE its noise} for t in
+          t_slices -- those few steps run through PyTorch ops (eagerly), all others as graph replays."""
+        start = None
+        if use_a_precomputed_XT:
+            if self.noise == 'cpu':
+                torch.normal(0, 1, size=size)          # util.sampling draws (and discards) x_T first: same CPU stream
+            z = torch.randn(size, device=self.device) if self.noise == 'device' else torch.normal(0, 1, size=size).to(self.device)
+            x_T = XT.to(self.device) + self._sigma_raw[step] * z
+            start = step - 1
+        slices = {}
+        want = set(int(t) for t in t_slices) if return_multiple_t_slices else set()
+        t0 = (self.T - 1) if start is None else start
+        keep = [] if t0 in want else None
+        self.begin(size, condition, label, x_T, start_step=start, keep_slice=keep)
+        if keep:
+            slices[t0] = keep[0]
+        while self.remaining > 0:
+            t = self.remaining - 1
+            if t in want:
+                keep = []
+                self._advance_eager(keep)
+                slices[t] = keep[0]
+            else:
+                self.advance(1)
+        out = self.finish()
+        return (out, slices) if return_multiple_t_slices else out
 
 
 class GraphedFastSampler(GraphedReverseSampler):

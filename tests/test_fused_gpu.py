@@ -230,6 +230,34 @@ def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
     assert ((a - b).abs() / (b.abs() + 1.0)).max() < 1e-5         # same kernels, same inputs
 
 
+def test_graphed_sampler_options_t_slices_and_precomputed_xt(cuda):
+    """GraphedReverseSampler.sample(return_multiple_t_slices=, use_a_precomputed_XT=) (util.py:217-222, 246-248): the
+    slice steps run eagerly through PyTorch ops, every other step as a graph replay; against the layer-by-layer
+    reference-style loop `util.sampling` on the same CPU noise stream."""
+    import contextlib, io
+    net, fused = _pair(small_fused_config(), 29, cuda)
+    dh = util.calc_diffusion_hyperparams(9, 1e-4, 0.02)
+    g = torch.Generator().manual_seed(12)
+    cond = torch.cat([torch.rand(2, 256, 3, generator=g) * 2 - 1, torch.ones(2, 256, 1)], 2).to(cuda)
+    label = torch.tensor([4, 9], device=cuda)
+    XT = torch.randn(2, 128, 3, generator=g).to(cuda)
+    kw = dict(return_multiple_t_slices=True, t_slices=[5, 1], use_a_precomputed_XT=True, step=7, XT=XT)
+    util.set_device(cuda)
+    util.set_noise_source('cpu')
+    try:
+        torch.manual_seed(41)
+        with contextlib.redirect_stdout(io.StringIO()):
+            want, want_slices = util.sampling(net, (2, 128, 3), dh, label=label, verbose=False, condition=cond, **kw)
+    finally:
+        util.set_device(None)
+    for use_graph in (True, False):
+        torch.manual_seed(41)
+        got, slices = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=use_graph).sample((2, 128, 3), cond, label, **kw)
+        assert sorted(slices) == [1, 5] == sorted(want_slices)
+        for a, b in [(got, want)] + [(slices[t], want_slices[t]) for t in (1, 5)]:
+            assert ((a - b).abs() / (b.abs() + 1.0)).max() < 2e-4, use_graph
+
+
 @pytest.mark.parametrize("fuse_branch", [False, True])
 def test_second_batch_with_other_labels_through_the_captured_graph(cuda, fuse_branch, monkeypatch):
     """The class-embedding rows of the blocks live in a static buffer that a captured step only READS: a second batch

@@ -510,5 +510,21 @@ def test_graphed_samplers_reproduce_the_eager_loops_on_the_cpu(method, schedule,
             torch.manual_seed(4)
             got = GraphedReverseSampler(net, dh6, noise='cpu', use_graph=False).sample((2, 64, 3), cond, label)
             assert torch.equal(got, want)
+            # the two options of util.sampling (:217-222, 246-248): t-slices (clouds before the step's noise) and a
+            # restart from a stored x^step
+            dh9 = util.calc_diffusion_hyperparams(9, 1e-4, 0.02)
+            XT = torch.randn(2, 64, 3, generator=g)
+            for kw in (dict(return_multiple_t_slices=True, t_slices=[8, 5, 2, 0]),
+                       dict(use_a_precomputed_XT=True, step=6, XT=XT),
+                       dict(return_multiple_t_slices=True, t_slices=[5, 1], use_a_precomputed_XT=True, step=6, XT=XT)):
+                torch.manual_seed(5)
+                want = util.sampling(net, (2, 64, 3), dh9, label=label, verbose=False, condition=cond, **kw)
+                torch.manual_seed(5)
+                got = GraphedReverseSampler(net, dh9, noise='cpu', use_graph=False).sample((2, 64, 3), cond, label, **kw)
+                if kw.get("return_multiple_t_slices"):
+                    assert torch.equal(got[0], want[0]) and sorted(got[1]) == sorted(want[1])
+                    assert all(torch.equal(got[1][t], want[1][t]) for t in want[1])
+                else:
+                    assert torch.equal(got, want)
     finally:
         util.set_device(None)
