@@ -287,6 +287,12 @@ int pdr_fused_layer_pool(const pdr_layer_in_t *in, long P, int Cin, const float 
                          const float *bias, int D, const float *values, int ldv, const float *vscale,
                          const float *vshift, int v_relu, const int *counts, int K, float *out,
                          int ldo, pdr_stream_t stream);
+/* the same with the score conv on split-bf16 arithmetic: Wp / nchunks = the packed weight image of
+ * pdr_fused_layer_bf16x3; 128-column wave-specialised tiles only (PDR_EUNSUPPORTED otherwise) */
+int pdr_fused_layer_pool_bf16x3(const pdr_layer_in_t *in, long P, int Cin, const void *Wp, int nchunks,
+                                const float *bias, int D, const float *values, int ldv,
+                                const float *vscale, const float *vshift, int v_relu, const int *counts,
+                                int K, float *out, int ldo, pdr_stream_t stream);
 /* chan_stats[b, coff+c] (double sum, double sumsq) = mult * sum over tiles of batch b;
  * `partial` points at the first of C columns inside rows of ldp columns */
 int pdr_gn_reduce(const float *partial, int ldp, int B, int tiles_per_batch, int C, double mult,

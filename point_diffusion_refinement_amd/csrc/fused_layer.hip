@@ -1051,7 +1051,7 @@ extern "C" int pdr_fused_layer_bf16x3(const pdr_layer_in_t* in, long P, int Cin,
   const int prc = plan_layer(in, P, Cin, reinterpret_cast<const float*>(Wp), (Cout + 3) & ~3, Cout, Y, ldy, &pl);
   if (prc != PDR_OK) return prc;
   if (P == 0) return PDR_OK;
-  if (!pl.ws || (pl.t.id != 4 && pl.t.id != 5)) return PDR_EUNSUPPORTED;
+  if (!pl.ws || (pl.t.id != 4 && pl.t.id != 5 && pl.t.id != 8)) return PDR_EUNSUPPORTED;
   int nch = 0;
   for (int s = 0; s < in->n_seg; ++s) nch += (in->seg[s].C + 31) / 32;
   if (nch != nchunks) return PDR_EINVAL;   // the image was packed for another segment structure
@@ -1065,6 +1065,43 @@ extern "C" int pdr_fused_layer_bf16x3(const pdr_layer_in_t* in, long P, int Cin,
 // scores = prologue(X) . Wt + bias are consumed by the POOL epilogue:
 //   out[q, :] = sum_k softmax_k(mask(scores))[k, :] * act(values[q K + k, :] * vscale + vshift)
 // K in {8, 16, 32}; Cout = D (channels of scores, values and out).
+// pdr_fused_layer_pool with the score conv on split-bf16 arithmetic (packed weight image as pdr_fused_layer_bf16x3);
+// the 128-column wave-specialised tiles only: PDR_EUNSUPPORTED otherwise (the caller uses the exact entry point).
+extern "C" int pdr_fused_layer_pool_bf16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
+                                           const float* bias, int D, const float* values, int ldv,
+                                           const float* vscale, const float* vshift, int v_relu,
+                                           const int* counts, int K, float* out, int ldo, pdr_stream_t stream) {
+  if (!in || !Wp || nchunks <= 0 || reinterpret_cast<uintptr_t>(Wp) % 16 != 0 || !values || !out || P <= 0 ||
+      Cin <= 0 || D <= 0 || in->n_seg < 1 || in->n_seg > 4 || ldv < D || ldo < D)
+    return PDR_EINVAL;
+  if (!(K == 8 || K == 16 || K == 32)) return PDR_EUNSUPPORTED;
+  if (in->rseg.ptr || in->oadd) return PDR_EUNSUPPORTED;
+  int ctot = 0, nch = 0;
+  bool vec = true;
+  for (int s = 0; s < in->n_seg; ++s) {
+    const pdr_seg_t& g = in->seg[s];
+    if (!g.ptr || g.C <= 0 || g.row_div != 1 || g.gV) return PDR_EUNSUPPORTED;
+    vec = vec && reinterpret_cast<uintptr_t>(g.ptr) % 16 == 0 && g.ld % 4 == 0 && g.ld >= ((g.C + 3) & ~3);
+    ctot += g.C;
+    nch += (g.C + 31) / 32;
+  }
+  if (ctot != Cin || in->rows_per_batch <= 0 || P % in->rows_per_batch != 0 || in->rows_per_batch % 32 != 0)
+    return PDR_EINVAL;
+  if (nch != nchunks) return PDR_EINVAL;   // the image was packed for another segment structure
+  if (!vec || !use_ws_kernels()) return PDR_EUNSUPPORTED;
+  const TileCfg t = pick_tile(in->rows_per_batch, D);
+  if ((t.id != 4 && t.id != 5 && t.id != 8) || in->rows_per_batch % t.tm != 0) return PDR_EUNSUPPORTED;
+  const long nb = P / in->rows_per_batch;
+  const long ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
+  const int ncol = (D + t.tn - 1) / t.tn;
+  PoolArgs pa{values, vscale, vshift, counts, out, ldv, ldo, K, v_relu};
+  if (!pdr::launch_fused_layer_ws(t.id, false, false, *in, Cin, reinterpret_cast<const float*>(Wp), nchunks, bias, D,
+                                  nullptr, 0, nullptr, D, static_cast<int>(ntiles), ncol, pdr::as_stream(stream), true,
+                                  &pa))
+    return PDR_EUNSUPPORTED;
+  return pdr::check_launch();
+}
+
 extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw,
                                     const float* bias, int D, const float* values, int ldv,
                                     const float* vscale, const float* vshift, int v_relu,

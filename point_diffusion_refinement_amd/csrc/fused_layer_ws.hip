@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
   constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
-  static_assert(!SPLIT || TN == 128, "split image: 128-column blocks");
+  static_assert(!SPLIT || TN == 128 || TN == 64, "split image: 128- or 64-column blocks");
   constexpr int C4 = KC / 4;          // float4 columns of an A chunk
   constexpr int PT = 256;             // producer threads: all four producer waves stage every chunk
   constexpr int VSTEP = PT / C4;      // rows covered per step
@@ -933,13 +933,13 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
 
 // Launches the wave-specialised kernel for tile variant `id`.  Returns false when the variant has no
 // wave-specialised instantiation.  split: bf16x3 arithmetic (Wt = packed weight image, ldw = chunks per column
-// block); instantiated for the 128-column tile variants 4 and 5 only.
+// block); instantiated for the 128-column tile variants 4 and 5 and the 64-column variant 8.
 bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
                            int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,
                            int relu_col0, int n_row_tiles, int ncol, hipStream_t s, bool split, const PoolArgs* pool) {
   if (!fused_layer_ws_supported(id, radd, gath, in, Cin)) return false;
-  if (split && id != 4 && id != 5) return false;
-  if (pool && (radd || gath || split || in.oadd)) return false;   // pooled epilogue: plain sources, exact arithmetic
+  if (split && id != 4 && id != 5 && id != 8) return false;
+  if (pool && (radd || gath || in.oadd)) return false;   // pooled epilogue: plain sources
   const PoolArgs pa = pool ? *pool : PoolArgs();
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
@@ -973,6 +973,16 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     else if (radd) PDR_WS_K(RT, CT, WR, WC, KC, true, 0, true); \
     else PDR_WS_K(RT, CT, WR, WC, KC, false, 0, true);        \
   } while (0)
+  if (pool && split) {
+#define PDR_WS_POOL_SPLIT(RT, CT, WR, WC, KC)                                                                  \
+  hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, true, true>), grid, dim3(512), 0, s, \
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
+    if (id == 4) PDR_WS_POOL_SPLIT(2, 2, 2, 2, 32);
+    else if (id == 5) PDR_WS_POOL_SPLIT(1, 2, 2, 2, 32);
+    else PDR_WS_POOL_SPLIT(1, 2, 4, 1, 32);
+#undef PDR_WS_POOL_SPLIT
+    return true;
+  }
   if (pool) {
     switch (id) {
       case 0: PDR_WS_POOL(2, 1, 4, 1, 16); return true;
@@ -987,7 +997,8 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   }
   if (split) {
     if (id == 4) PDR_WS_SPLIT(2, 2, 2, 2, 32);
-    else PDR_WS_SPLIT(1, 2, 2, 2, 32);
+    else if (id == 5) PDR_WS_SPLIT(1, 2, 2, 2, 32);
+    else PDR_WS_SPLIT(1, 2, 4, 1, 32);
     return true;
   }
   switch (id) {

@@ -716,11 +716,13 @@ def test_attention_pool_matches_masked_softmax(cuda, B, npoint, K, D, ld, use_co
 # ------------------------------------------------------------------ split-bf16 (opt-in) arithmetic
 @pytest.mark.parametrize("P,Cin,Cout,rpb,segs", [(1024, 128, 128, 256, (128,)), (2048, 331, 331, 1024, (171, 160)),
                                                  (512, 512, 512, 64, (512,)), (4096, 203, 128, 4096, (200, 3)),
-                                                 (1 << 16, 256, 256, 8192, (128, 128))])
+                                                 (1 << 16, 256, 256, 8192, (128, 128)),
+                                                 (4096, 256, 64, 1024, (256,)), (2048, 140, 64, 256, (128, 12))])
 def test_split_bf16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch):
     """pdr_fused_layer_bf16x3 (x . w = xh wh + xh wl + xl wh on bf16 MFMA, fp32 accumulate): every element within
     1e-4 of the float64 result RELATIVE TO THE ROW's |x| . |w| scale (the exact fp32 kernel sits at ~1e-6), incl.
-    multi-segment inputs, a partial last chunk, the prologue and a residual; statistics as in the exact kernel."""
+    multi-segment inputs, a partial last chunk, the prologue and a residual; statistics as in the exact kernel.
+    The last two shapes run on the 64-column tile variant (64-column weight image)."""
     g = torch.Generator().manual_seed(Cin * 3 + Cout)
     B = P // rpb
     xs, off = [], 0
