@@ -95,8 +95,16 @@ __device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ (
 // GATH: 0 = plain sources, 1 = gathered ball-query first conv (U[idx] + V, empty balls), 2 = gathered kNN first conv
 // (U[idx] + V + d2 r1 + w r2: the two per-position terms of group_knn's distance / weight channels)
 // POOL: attention pooling epilogue (pdr::PoolArgs) -- the scores stay in the accumulators
+// Workgroups per CU: two (4 waves per SIMD, 128 registers) for every tile shape but the 128 x 32 narrow tiles without a
+// residual source: those are bound by the latency of their single chunk in flight, hold 16 accumulators and fit 80
+// registers and 51 KB of LDS, so THREE workgroups per CU (6 waves per SIMD) keep half as many chunks again in flight:
+// 8.69 / 8.68 / 8.67 -> 8.54 / 8.56 / 8.59 ms per step (split-bf16 step 7.25 -> 7.07).  The residual forms need 92-200
+// bytes of scratch per lane under the 80-register cap and lose (8.6 -> 9.1 ms): they stay at two.
+template <int RT, int CT, bool RADD, bool SPLIT>
+constexpr int ws_waves_per_simd() { return (RT * CT == 1 && !RADD && !SPLIT) ? 6 : 4; }
+
 template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool SPLIT = false, bool POOL = false>
-__global__ __launch_bounds__(512, 4) void fused_layer_ws_kernel(
+__global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
     float* __restrict__ partial, int relu_col0, int n_row_tiles, pdr::PoolArgs pool) {
@@ -943,7 +951,14 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   const PoolArgs pa = pool ? *pool : PoolArgs();
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
-  const long cap = (512 + ncol - 1) / ncol;
+  // persistent: every workgroup co-resident -- 2 per CU, 3 for the narrow tiles without a residual (see above);
+  // PDR_WS_NARROW3=0: 2 for all (A/B)
+  static const bool narrow3 = [] {
+    const char* e = getenv("PDR_WS_NARROW3");
+    return !(e && e[0] == '0');
+  }();
+  const long resident = (narrow3 && id == 7 && !radd && !split) ? 768 : 512;
+  const long cap = (resident + ncol - 1) / ncol;
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
