@@ -23,7 +23,7 @@
  *   - return value: PDR_OK (0) or a negative PDR_E* code.  Nothing prints or
  *     calls exit() (contrast cuda_utils.h:30-39).  No hidden allocation, no
  *     device synchronisation, no mutable global state: calls are thread-safe and
- *     capturable into a hipGraph.  The only process-wide inputs are five tuning
+ *     capturable into a hipGraph.  The only process-wide inputs are seven tuning
  *     knobs read ONCE from the environment (kernel selection only; results are
  *     identical, for the layer kernels and the GroupNorm fold up to fp32 / fp64
  *     summation order):
@@ -31,8 +31,11 @@
  *     tiles for outputs of <= 64 channels, see pdr_fused_layer_tile_rows),
  *     PDR_FPS_WAVE=0|2 (furthest-point-sampling kernel family, see
  *     pdr_furthest_point_sampling), PDR_KNN_WAVE=0 (thread-per-query instead of
- *     wave-per-query kNN for K <= 8) and PDR_GN_FOLD_SMALL=0 (1024-thread
- *     GroupNorm fold workgroups).
+ *     wave-per-query kNN for K <= 8), PDR_GN_FOLD_SMALL=0 (1024-thread
+ *     GroupNorm fold workgroups), PDR_WS_NARROW3=0 (two instead of three
+ *     co-resident workgroups per CU for the 128 x 32 tiles) and
+ *     PDR_WS_XCD_ORDER=0|2 (tile order of the layer kernels: plain / XCD-local
+ *     for every layer instead of for the gathered ones).
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined
  *     behaviour, as in the reference's kernels).

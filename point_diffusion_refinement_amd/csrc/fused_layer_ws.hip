@@ -107,7 +107,7 @@ template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool 
 __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) void fused_layer_ws_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int n_row_tiles, pdr::PoolArgs pool) {
+    float* __restrict__ partial, int relu_col0, int n_row_tiles, int tile_order, pdr::PoolArgs pool) {
   // SPLIT: `Wt` points at the packed bf16 hi / lo weight image (pdr_pack_weights_bf16x3: per column block and
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
@@ -134,8 +134,22 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   // chunks per tile, tiles of this workgroup
   int nch = 0;
   for (int s = 0; s < in.n_seg; ++s) nch += (in.seg[s].C + KC - 1) / KC;
+  // Tile order.  A workgroup walks LOCAL tile numbers l = first + k step (k = 0 .. my_tiles - 1); local -> row tile:
+  //   plain      first = blockIdx.x, step = gridDim.x, row tile = l: at any moment the resident workgroups work on
+  //              consecutive tiles of ONE cloud (and every XCD's L2 fetches that cloud's gathered table);
+  //   XCD-local  workgroup ids are dealt to the 8 XCDs round-robin (id % 8 == XCC id, tools/lab/xcc_probe.hip), so
+  //              XCD x owns the clouds x, x + 8, ...: first = blockIdx.x / 8, step = gridDim.x / 8, and local tile l
+  //              is tile l % tpb of cloud x + 8 (l / tpb) -- a cloud's gathered table is fetched into ONE L2.
+  // Same cost per chunk either way (one division by tpb); no change of which rows a tile holds.
   const int nwg = static_cast<int>(gridDim.x);
-  const int my_tiles = (n_row_tiles - static_cast<int>(blockIdx.x) + nwg - 1) / nwg;
+  const int nB = n_row_tiles / tpb;
+  const bool xcd_order = tile_order != 0 && (nwg & 7) == 0 && nB >= 8;   // uniform
+  const int xcd = static_cast<int>(blockIdx.x) & 7;
+  const int tile_first = xcd_order ? static_cast<int>(blockIdx.x) >> 3 : static_cast<int>(blockIdx.x);
+  const int tile_step = xcd_order ? nwg >> 3 : nwg;
+  const int tile_limit = xcd_order ? ((nB - xcd + 7) >> 3) * tpb : n_row_tiles;   // local tiles of this walk
+  const int cloud_mul = xcd_order ? 8 : 1, cloud_add = xcd_order ? xcd : 0;
+  const int my_tiles = tile_limit > tile_first ? (tile_limit - tile_first + tile_step - 1) / tile_step : 0;
   const int G = my_tiles * nch;
   const bool has_partial = partial != nullptr;
   if (tid == 0) epi_ticket = 0;       // ordered before its first use by the barrier B(0)
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     n.ks = seg_end ? 0 : ks1;
     n.cbase = tile_end ? 0 : (seg_end ? c.cbase + segC : c.cbase);
     n.sg = tile_end ? 0 : (seg_end ? c.sg + 1 : c.sg);
-    n.tile = tile_end ? c.tile + static_cast<int>(gridDim.x) : c.tile;
+    n.tile = tile_end ? c.tile + tile_step : c.tile;
     n.ci = tile_end ? 0 : c.ci + 1;
     c.ci = really ? n.ci : c.ci;
     c.ks = really ? n.ks : c.ks;
@@ -243,7 +257,8 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
     // fetch: chunk at cursor c -> registers (address arithmetic + loads only)
     auto fetch = [&](const Cur& c) __attribute__((always_inline)) {
-      const int b = c.tile / tpb, tb = c.tile - b * tpb;
+      const int bl = c.tile / tpb, tb = c.tile - bl * tpb;
+      const int b = bl * cloud_mul + cloud_add;
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
       const pdr_seg_t seg = in.seg[c.sg];
@@ -284,9 +299,10 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
           }
           g_tile = c.tile;
         }
-        const int nt = c.tile + static_cast<int>(gridDim.x);
-        if (GATH == 1 && last_of_tile(c) && nt < n_row_tiles) { // uniform: prefetch the next tile's indices
-          const int nb = nt / tpb, ntb = nt - nb * tpb;
+        const int nt = c.tile + tile_step;
+        if (GATH == 1 && last_of_tile(c) && nt < tile_limit) {  // uniform: prefetch the next tile's indices
+          const int nbl = nt / tpb, ntb = nt - nbl * tpb;
+          const int nb = nbl * cloud_mul + cloud_add;
           const long nrow0 = static_cast<long>(nb) * rpb + static_cast<long>(ntb) * TM;
           const int nnv = min(TM, rpb - ntb * TM);
           if constexpr (GATH == 1) load_idx(nrow0, nnv, n_idx, n_cnt);
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     // the next chunk, barrier.  The staging math is spread over all four producer waves because its
     // LATENCY (not its issue cost) is what can delay the barrier: next to two MFMA-bound waves a
     // VALU instruction waits ~a whole MFMA issue slot.
-    Cur co{static_cast<int>(blockIdx.x), 0, 0, 0, 0};
+    Cur co{tile_first, 0, 0, 0, 0};
     fetch(co);
     for (int g = 0; g < G; ++g) {
       PDR_T(1, 4 * g + 0);
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_r[j];
 
-  Cur cur{static_cast<int>(blockIdx.x), 0, 0, 0, 0};
+  Cur cur{tile_first, 0, 0, 0, 0};
   for (int g = 0; g < G; ++g) {
     PDR_T(0, 4 * g + 0);
     __syncthreads();   // B(g)
@@ -629,8 +645,9 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     PDR_T(0, 4 * g + 2);
     if (last_of_tile(cur)) {
       // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)
-      const int tile = cur.tile;
-      const int b = tile / tpb, tb = tile - b * tpb;
+      const int bl = cur.tile / tpb, tb = cur.tile - bl * tpb;
+      const int b = bl * cloud_mul + cloud_add;
+      const int tile = b * tpb + tb;           // row tile (index of its partial row)
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
       const bool rows_full = nvalid == TM;   // uniform
@@ -958,15 +975,26 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     return !(e && e[0] == '0');
   }();
   const long resident = (narrow3 && id == 7 && !radd && !split) ? 768 : 512;
-  const long cap = (resident + ncol - 1) / ncol;
+  // PDR_WS_XCD_ORDER: 1 (default) = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer,
+  // 0 = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
+  // (143 MB algorithmic), of the kNN-gathered narrow tiles 178 -> 143 MB, ball-gathered kernels unchanged; step time
+  // 8.75 / 8.75 / 8.76 (plain) vs 8.79 / 8.69 / 8.78 (gathered kernels) vs 8.80 / 8.80 / 8.79 (all).  Results are
+  // bit-identical (tools/lab/order_check.py).
+  static const int xcd_knob = [] {
+    const char* e = getenv("PDR_WS_XCD_ORDER");
+    return e ? atoi(e) : 1;
+  }();
+  const int tile_order = (xcd_knob >= 2 || (xcd_knob == 1 && gath)) ? 1 : 0;
+  long cap = (resident + ncol - 1) / ncol;
+  if (tile_order) cap = cap / 8 * 8;
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
 #define PDR_WS_POOL(RT, CT, WR, WC, KC)                                                                       \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   const bool knn_res = in.rseg.gV && in.rseg.g_r1;
@@ -991,7 +1019,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   if (pool && split) {
 #define PDR_WS_POOL_SPLIT(RT, CT, WR, WC, KC)                                                                  \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, true, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
     if (id == 4) PDR_WS_POOL_SPLIT(2, 2, 2, 2, 32);
     else if (id == 5) PDR_WS_POOL_SPLIT(1, 2, 2, 2, 32);
     else PDR_WS_POOL_SPLIT(1, 2, 4, 1, 32);
