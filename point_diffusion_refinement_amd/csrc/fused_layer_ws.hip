@@ -143,13 +143,17 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   // Same cost per chunk either way (one division by tpb); no change of which rows a tile holds.
   const int nwg = static_cast<int>(gridDim.x);
   const int nB = n_row_tiles / tpb;
-  const bool xcd_order = tile_order != 0 && (nwg & 7) == 0 && nB >= 8;   // uniform
+  // (whole groups of 8 clouds only: otherwise some XCDs would own fewer clouds than others)
+  const bool xcd_order = tile_order != 0 && (nwg & 7) == 0 && nB >= 8 && (nB & 7) == 0;   // uniform
   const int xcd = static_cast<int>(blockIdx.x) & 7;
   const int tile_first = xcd_order ? static_cast<int>(blockIdx.x) >> 3 : static_cast<int>(blockIdx.x);
   const int tile_step = xcd_order ? nwg >> 3 : nwg;
   const int tile_limit = xcd_order ? ((nB - xcd + 7) >> 3) * tpb : n_row_tiles;   // local tiles of this walk
   const int cloud_mul = xcd_order ? 8 : 1, cloud_add = xcd_order ? xcd : 0;
   const int my_tiles = tile_limit > tile_first ? (tile_limit - tile_first + tile_step - 1) / tile_step : 0;
+  // (XCD-local order with more workgroups per XCD than local tiles: nothing to do -- and the producers' first fetch
+  // below must not run on a tile that does not exist)
+  if (my_tiles == 0) return;
   const int G = my_tiles * nch;
   const bool has_partial = partial != nullptr;
   if (tid == 0) epi_ticket = 0;       // ordered before its first use by the barrier B(0)

@@ -594,7 +594,9 @@ def test_narrow_layers_on_128_row_tiles(cuda, kind):
             assert _rel(st[..., 0], s1) < 2e-4 and _rel(st[..., 1], s2) < 2e-4, (kind, B, rpb, Cin, Cout, seed)
 
 
-@pytest.mark.parametrize("B,rpb,Cin,Cout", [(2, 256, 128, 128), (3, 64, 256, 256), (2, 1024, 100, 140), (2, 384, 64, 96)])
+# (B = 8 / 16 / 24: whole groups of 8 clouds take the XCD-local tile order of the gathered kernels; 10: the plain one)
+@pytest.mark.parametrize("B,rpb,Cin,Cout", [(2, 256, 128, 128), (3, 64, 256, 256), (2, 1024, 100, 140), (2, 384, 64, 96),
+                                            (8, 256, 128, 128), (16, 128, 64, 96), (24, 512, 128, 128), (10, 256, 128, 128)])
 @pytest.mark.parametrize("kind", ["rgath", "rknn"])
 def test_gathered_residual_on_wide_tiles(cuda, B, rpb, Cin, Cout, kind):
     """A gathered residual (the residual conv of a virtual first conv) through the 128- / 64-row wide tiles and
