@@ -34,8 +34,8 @@
  *     wave-per-query kNN for K <= 8), PDR_GN_FOLD_SMALL=0 (1024-thread
  *     GroupNorm fold workgroups), PDR_WS_NARROW3=0 (two instead of three
  *     co-resident workgroups per CU for the 128 x 32 tiles) and
- *     PDR_WS_XCD_ORDER=0|2 (tile order of the layer kernels: plain / XCD-local
- *     for every layer instead of for the gathered ones).
+ *     PDR_WS_XCD_ORDER=1|2 (XCD-local tile order of the gathered / of all layer
+ *     kernels instead of the plain one).
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined
  *     behaviour, as in the reference's kernels).
