@@ -230,6 +230,24 @@ def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
     assert ((a - b).abs() / (b.abs() + 1.0)).max() < 1e-5         # same kernels, same inputs
 
 
+def test_xcd_local_tile_order_is_bit_identical(cuda, tmp_path):
+    """PDR_WS_XCD_ORDER (read once per process -> two subprocesses): the XCD-local cloud-major tile order of the layer
+    kernels changes WHICH workgroup computes a tile, never the tile: one uncached + three cached reverse steps of the
+    DDPM config at B = 8 give identical bytes under the plain order and under the XCD-local order for every layer."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for order in ("0", "2"):
+        path = str(tmp_path / ("x%s.pt" % order))
+        env = dict(os.environ, PDR_WS_XCD_ORDER=order, ORDER_CHECK_B="8")
+        subprocess.check_call([sys.executable, "-m", "tools.lab.order_check", path], cwd=root, env=env,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        outs.append(torch.load(path))
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
 def test_graphed_sampler_options_t_slices_and_precomputed_xt(cuda):
     """GraphedReverseSampler.sample(return_multiple_t_slices=, use_a_precomputed_XT=) (util.py:217-222, 246-248): the
     slice steps run eagerly through PyTorch ops, every other step as a graph replay; against the layer-by-layer
