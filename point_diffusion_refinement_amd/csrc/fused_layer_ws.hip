@@ -982,9 +982,9 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   // PDR_WS_XCD_ORDER: 1 = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer, 0 (default)
   // = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
   // (143 MB algorithmic), of the kNN-gathered narrow tiles 178 -> 143 MB, ball-gathered kernels unchanged; step time
-  // 8.75 / 8.75 / 8.76 (plain) vs 8.79 / 8.69 / 8.78 (gathered kernels) vs 8.80 / 8.80 / 8.79 (all) -- but the
-  // dominant kernel ALONE on the chip takes 148.3 instead of 139.8 us (eight concurrent row streams instead of one),
-  // so the plain order stays the default.  Results are bit-identical (tools/lab/order_check.py).
+  // 8.75 / 8.75 / 8.76 (plain) vs 8.79 / 8.69 / 8.78 (gathered kernels) vs 8.80 / 8.80 / 8.79 (all); the dominant
+  // kernel alone on the chip 149.3 / 149.3 us (plain) vs 152.3 / 149.8 us: fewer bytes, no time gained (MFMA-bound),
+  // so the plain order stays the default.  Results are bit-identical (tools/lab/order_check.py, tests).
   static const int xcd_knob = [] {
     const char* e = getenv("PDR_WS_XCD_ORDER");
     return e ? atoi(e) : 0;
