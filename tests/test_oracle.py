@@ -247,3 +247,33 @@ def test_knn_grad_is_the_adjoint_of_the_squared_distances(n1, n2, K):
     (d * torch.tensor(g, dtype=torch.float64) * valid).sum().backward()
     np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(gy, yt.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_discrete_decision_replay_detects_a_flip_and_only_there():
+    """tests/parity.py (the bookkeeping the GPU parity tests rely on): identical trajectories -> no flipped cloud; a
+    1e-7 perturbation of a generic cloud -> still none; moving ONE point of ONE cloud across a ball boundary / onto a
+    different FPS rank -> exactly that cloud is reported, with the step and the decision that changed."""
+    import torch
+    from tests import parity
+    from tests.golden import inputs as I
+    from tests.golden.tiny_config import tiny_pointnet_config
+    cfg = tiny_pointnet_config()
+    x, cond, _, _ = I.network_inputs()
+    xs = [x.clone(), (x * 0.9).clone(), (x * 0.8).clone()]
+    flipped, first = parity.flipped_clouds(cfg, xs, [t.clone() for t in xs], cond)
+    assert not flipped.any() and first == [None, None]
+    tiny = [t * (1 + 1e-7) for t in xs]
+    assert not parity.flipped_clouds(cfg, xs, tiny, cond)[0].any()
+    moved = [t.clone() for t in xs]
+    moved[1][1, 5] += torch.tensor([0.8, -0.6, 0.7])              # cloud 1, call 1: one point far away
+    flipped, first = parity.flipped_clouds(cfg, xs, moved, cond)
+    assert flipped.tolist() == [False, True] and first[0] is None and first[1][0] == 1
+    # rel_err / check: per-cloud scale, bound enforced, record kept
+    n0 = len(parity.RECORDS)
+    want = torch.randn(2, 50, 3, generator=torch.Generator().manual_seed(1))
+    rec = parity.check("unit", "cpu", want * (1 + 5e-6), want, 1e-4)
+    assert rec["max_rel"] < 6e-6 and rec["margin"] > 15 and len(parity.RECORDS) == n0 + 1
+    import pytest
+    with pytest.raises(AssertionError):
+        parity.check("unit_fail", "cpu", want + 1e-2, want, 1e-4)
+    del parity.RECORDS[n0:]                                          # keep the session's parity dump clean
