@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
   const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= npoints * 3) return;
   const long long t = *t_ptr;
+  if (t < 0) return;   // a replay past the last step: leave x alone rather than index the tables at -1
   const float a = tab_a[t], b = tab_b[t], c = tab_c[t];
   const long p = i / 3;
   const int d = static_cast<int>(i - p * 3);
@@ -68,7 +69,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
-__device__ __forceinline__ float u01(unsigned v) {   // (0, 1): 24 bits + half an ulp
+// (0, 1]: 24 bits + half an ulp (the top value rounds to 1.0f, whose log is 0 -- never 0.0f, whose log is -inf)
+__device__ __forceinline__ float u01(unsigned v) {
   return static_cast<float>(v >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
 
@@ -85,9 +87,11 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(float* __restrict__ x
                                                            long total) {
   const long quad = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   const long long t = *t_ptr;
-  const float a = tab_a[t], b = tab_b[t], c = tab_c[t];
+  // t < 0 is a replay past the last step: x is left alone (the tables are not indexed at -1), the ticket still runs
+  const long long tt = t < 0 ? 0 : t;
+  const float a = tab_a[tt], b = tab_b[tt], c = tab_c[tt];
   float zz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (quad * 4 < total) {
+  if (t >= 0 && quad * 4 < total) {
     if (rng) {
       const unsigned long long seed = rng[0], draw = rng[1];
       unsigned r[4];

@@ -257,6 +257,8 @@ class GraphedReverseSampler:
           t_slices -- those few steps run through PyTorch ops (eagerly), all others as graph replays."""
         start = None
         if use_a_precomputed_XT:
+            if XT is None or not 1 <= int(step) <= self.T - 1:
+                raise ValueError("use_a_precomputed_XT needs XT (the stored x^step) and 1 <= step <= T-1")
             if self.noise == 'cpu':
                 torch.normal(0, 1, size=size)          # util.sampling draws (and discards) x_T first: same CPU stream
             z = torch.randn(size, device=self.device) if self.noise == 'device' else torch.normal(0, 1, size=size).to(self.device)
