@@ -21,7 +21,7 @@ Rank 0 prints one JSON line.  At N=1 rank 0 also reports
     every C-ABI launch of an eager step), against its roof;
   * `cpu_baseline`: the CPU port (this repo's PyTorch-CPU network over the C oracle ops) on
     the host cores, on a bounded sample of the same workload;
-  * `split_bf16`: the same step with the wide GEMMs in the opt-in bf16x3 MFMA mode (labelled,
+  * `split_f16`: the same step with the wide GEMMs in the opt-in f16x3 MFMA mode (labelled,
     never the headline);
   * `config3_eval` / `config5_fastdpm_refine`: BASELINE configs[2] and configs[4] on one GPU with
     their own bounded CPU baselines.
@@ -55,12 +55,12 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--unfused", action="store_true",
                     help="layer-by-layer PyTorch execution over the native ops instead of the fused kernels")
-    ap.add_argument("--precision", choices=("f32", "split_bf16"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "split_f16"), default="f32",
                     help="arithmetic of the wide 1x1-conv GEMMs of the HEADLINE run (default exact fp32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the live roofline of the dominant kernel")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the split-bf16 / config-3 / config-5 legs (N=1 only)")
+                    help="skip the split-f16 / config-3 / config-5 legs (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--dry", action="store_true",
                     help="host-logic check without a GPU (tests): gloo backend, no sampler, synthetic metric "
@@ -344,7 +344,7 @@ def main():
         "metric": "DDPM reverse steps/sec (T=1000, N=2048)", "value": round(value, 2), "unit": "cloud-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "bf16x3 (wide GEMMs) + f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "f32" else "f16x3 (wide GEMMs) + f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: B=%d/GPU, N=2048, 3072-pt mirrored condition, T=1000 DDPM "
                                "reverse sampling, random-init dual-path PointNet++ (9.76 M params), cached "
                                "condition step" % B,
@@ -371,18 +371,21 @@ def main():
             out["roofline"] = {"error": repr(e)}
     if solo and not args.no_extras and not args.unfused and args.precision == "f32":
         try:
-            s2, _ = build_sampler(device, not args.no_graph, precision="split_bf16")
+            s2, _ = build_sampler(device, not args.no_graph, precision="split_f16")
             el2, _ = timed_steps(s2, args.steps, args.warmup)
-            out["split_bf16"] = {"value": round(B * args.steps / el2, 2), "unit": "cloud-steps/s",
+            out["split_f16"] = {"value": round(B * args.steps / el2, 2), "unit": "cloud-steps/s",
                                  "ms_per_step": round(el2 / args.steps * 1e3, 4),
                                  "completed_points_per_s_per_gpu": round(B * args.steps / el2 * N_POINTS / T_STEPS, 2),
-                                 "dtype": "bf16x3 MFMA (hi/lo split of both operands, fp32 accumulate) for the 128-column "
-                                          "GEMM tiles with Cin >= 128, exact fp32 MFMA elsewhere",
-                                 "note": "opt-in precision='split_bf16', NOT the headline; parity bar in "
-                                         "tests/test_fused_gpu.py::test_split_bf16_*"}
+                                 "dtype": "f16x3 MFMA (both operands as f16 hi + lo, 3 products, fp32 accumulate: ~22 "
+                                          "mantissa bits) for the 128- / 64-column GEMM tiles with Cin >= 64, exact fp32 "
+                                          "MFMA elsewhere",
+                                 "note": "opt-in precision='split_f16', NOT the headline; held to the exact mode's "
+                                         "parity bars (tests/test_fused_gpu.py::test_split_f16_*, the full-size "
+                                         "reference goldens of tests/test_reference_golden.py; margins in "
+                                         "profiles/r3_parity.json)"}
             del s2
         except Exception as e:
-            out["split_bf16"] = {"error": repr(e)}
+            out["split_f16"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         for key, fn in (("config3_eval", lambda: config3_eval(device, args.cpu_seconds)),
                         ("config5_fastdpm_refine", lambda: config5_fastdpm_refine(device, B))):

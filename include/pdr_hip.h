@@ -256,7 +256,7 @@ int pdr_fused_layer_variant(int rows_per_batch, int Cout);
 /* The launch pdr_fused_layer would make for these arguments, without launching (profilers attribute a call
  * to its kernel symbol): out[0..6] (8 ints of space) = {wave-specialised kernel (csrc/fused_layer_ws.hip)?,
  * tile variant id, residual source?, gathered source (0 none, 1 ball form, 2 kNN form), float4 staging?,
- * split-bf16 arithmetic?, thin kernel (<= 4 input channels, no prologue; used when `partial` is NULL)?}.
+ * split-f16 arithmetic?, thin kernel (<= 4 input channels, no prologue; used when `partial` is NULL)?}.
  * Same return codes as pdr_fused_layer.  Process-wide tuning knob read once: PDR_FUSED_WS=0 selects the uniform-wave kernels. */
 int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw, int Cout,
                          const float *Y, int ldy, int *out);
@@ -268,17 +268,21 @@ int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float 
 int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,
                     int relu_col0, pdr_stream_t stream);
-/* pdr_fused_layer in SPLIT-bf16 arithmetic (opt-in, never the default): x . w is evaluated as xh wh + xh wl + xl wh
- * with xh = bf16(x), xl = bf16(x - xh) (same for w) on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- about 16
- * mantissa bits per product instead of 24.  `Wp`: the weights packed by the caller, 16-byte aligned: for every
- * 128-column block cb and every K-chunk c (the input segments in order, each cut into chunks of 32 channels, the
- * last one zero-padded) one 16-KiB block  [hi | lo] x [128 columns][32 k] bf16 (k contiguous, 64-byte rows) whose
+/* pdr_fused_layer in SPLIT-f16 arithmetic (opt-in, never the default): x . w is evaluated as xh wh + xh wl + xl wh
+ * with xh = f16(x), xl = f16(x - xh) (same for w) on v_mfma_f32_32x32x16_f16, fp32 accumulation: every operand is
+ * held to max(2^-23 |x|, 2^-25) (two 11-bit halves; the MFMA honours the subnormal lo parts), the dropped xl wl term
+ * is 2^-22 relative -- fp32-class products at 3/16 of the fp32 MFMA cycles, PROVIDED the operands are of ordinary
+ * magnitude: |x| < 65504 after the prologue, and inputs whose rms is below ~1e-3 lose relative accuracy to the
+ * 2^-25 absolute floor (the fused network feeds these layers GroupNorm outputs, coordinates and embeddings).
+ * `Wp`: the weights packed by the caller, 16-byte aligned: for every column block cb (128 columns; 64 for tile
+ * variant 8) and every K-chunk c (the input segments in order, each cut into chunks of 32 channels, the
+ * last one zero-padded) one block  [hi | lo] x [columns][32 k] halves (k contiguous, 64-byte rows) whose
  * 16-byte granule g of column n is stored at position g ^ ((n >> 2) & 3);  block index = cb * nchunks + c.
- * Available for the 128-column wave-specialised tiles (pdr_fused_layer_variant 4 and 5); returns PDR_EUNSUPPORTED
+ * Available for the wave-specialised tile variants 4, 5 and 8 (pdr_fused_layer_variant); returns PDR_EUNSUPPORTED
  * otherwise -- callers then use pdr_fused_layer. */
-int pdr_fused_layer_bf16x3(const pdr_layer_in_t *in, long P, int Cin, const void *Wp, int nchunks,
-                           const float *bias, int Cout, float *Y, int ldy, float *partial, int relu_col0,
-                           pdr_stream_t stream);
+int pdr_fused_layer_f16x3(const pdr_layer_in_t *in, long P, int Cin, const void *Wp, int nchunks,
+                          const float *bias, int Cout, float *Y, int ldy, float *partial, int relu_col0,
+                          pdr_stream_t stream);
 /* pdr_fused_layer whose output (the attention scores, D channels) is consumed in the epilogue:
  * out[q,:] = sum_k softmax_k(mask(scores))[k,:] * act(values[q*K+k,:]*vscale + vshift); the (P x D)
  * score tensor is never written.  K in {8,16,32}; counts (P/K) or NULL = all neighbours valid.
@@ -290,12 +294,12 @@ int pdr_fused_layer_pool(const pdr_layer_in_t *in, long P, int Cin, const float 
                          const float *bias, int D, const float *values, int ldv, const float *vscale,
                          const float *vshift, int v_relu, const int *counts, int K, float *out,
                          int ldo, pdr_stream_t stream);
-/* the same with the score conv on split-bf16 arithmetic: Wp / nchunks = the packed weight image of
- * pdr_fused_layer_bf16x3; 128-column wave-specialised tiles only (PDR_EUNSUPPORTED otherwise) */
-int pdr_fused_layer_pool_bf16x3(const pdr_layer_in_t *in, long P, int Cin, const void *Wp, int nchunks,
-                                const float *bias, int D, const float *values, int ldv,
-                                const float *vscale, const float *vshift, int v_relu, const int *counts,
-                                int K, float *out, int ldo, pdr_stream_t stream);
+/* the same with the score conv on split-f16 arithmetic: Wp / nchunks = the packed weight image of
+ * pdr_fused_layer_f16x3; 128-column wave-specialised tiles only (PDR_EUNSUPPORTED otherwise) */
+int pdr_fused_layer_pool_f16x3(const pdr_layer_in_t *in, long P, int Cin, const void *Wp, int nchunks,
+                               const float *bias, int D, const float *values, int ldv,
+                               const float *vscale, const float *vshift, int v_relu, const int *counts,
+                               int K, float *out, int ldo, pdr_stream_t stream);
 /* chan_stats[b, coff+c] (double sum, double sumsq) = mult * sum over tiles of batch b;
  * `partial` points at the first of C columns inside rows of ldp columns */
 int pdr_gn_reduce(const float *partial, int ldp, int B, int tiles_per_batch, int C, double mult,

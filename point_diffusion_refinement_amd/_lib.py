@@ -45,9 +45,9 @@ SIGNATURES = {
     "pdr_fused_layer_variant": (_I, [_I, _I]),
     "pdr_fused_layer_plan": (_I, [_P, _c.c_long, _I, _P, _I, _I, _P, _I, _P]),
     "pdr_fused_layer": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
-    "pdr_fused_layer_bf16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "pdr_fused_layer_f16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pdr_fused_layer_pool": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
-    "pdr_fused_layer_pool_bf16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "pdr_fused_layer_pool_f16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "pdr_gn_reduce": (_I, [_P, _I, _I, _I, _I, _c.c_double, _P, _I, _I, _P]),
     "pdr_apply_act": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
     "pdr_gn_fold": (_I, [_P, _I, _I, _I, _c.c_double, _P, _I, _I, _I, _c.c_double, _I, _I, _I, _c.c_double, _F,

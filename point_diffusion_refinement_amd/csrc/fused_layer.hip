@@ -949,7 +949,7 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
 }  // namespace
 
 // out[0..6] = {wave-specialised kernel?, tile variant id, residual source?, gathered source (0 no / 1 ball / 2 kNN),
-// float4 staging?, split-bf16 arithmetic?, thin kernel when called without `partial`?} of the launch
+// float4 staging?, split-f16 arithmetic?, thin kernel when called without `partial`?} of the launch
 // pdr_fused_layer would make for these arguments.
 extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw, int Cout,
                                     const float* Y, int ldy, int* out) {
@@ -1037,14 +1037,14 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   return pdr::check_launch();
 }
 
-// pdr_fused_layer with SPLIT-bf16 arithmetic (opt-in): both GEMM operands are split into bf16 hi + lo parts and the
-// product is accumulated as xh wh + xh wl + xl wh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~16 mantissa
+// pdr_fused_layer with SPLIT-f16 arithmetic (opt-in): both GEMM operands are split into f16 hi + lo parts and the
+// product is accumulated as xh wh + xh wl + xl wh on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~22 mantissa
 // bits kept).  Wp = weight image of pdr-side packing (see include/pdr_hip.h), nchunks = K-chunks per column block.
-// Only the 128-column wave-specialised tiles carry this mode: PDR_EUNSUPPORTED otherwise (callers fall back to
+// Only the wave-specialised tile variants 4, 5 and 8 carry this mode: PDR_EUNSUPPORTED otherwise (callers fall back to
 // the exact fp32 entry point).
-extern "C" int pdr_fused_layer_bf16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
-                                      const float* bias, int Cout, float* Y, int ldy, float* partial,
-                                      int relu_col0, pdr_stream_t stream) {
+extern "C" int pdr_fused_layer_f16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
+                                     const float* bias, int Cout, float* Y, int ldy, float* partial,
+                                     int relu_col0, pdr_stream_t stream) {
   if (!Y || !Wp || nchunks <= 0 || reinterpret_cast<uintptr_t>(Wp) % 16 != 0) return PDR_EINVAL;
   LayerPlan pl;
   // (the fp32 weight arguments of the plan are placeholders: alignment-clean dummies)
@@ -1065,12 +1065,12 @@ extern "C" int pdr_fused_layer_bf16x3(const pdr_layer_in_t* in, long P, int Cin,
 // scores = prologue(X) . Wt + bias are consumed by the POOL epilogue:
 //   out[q, :] = sum_k softmax_k(mask(scores))[k, :] * act(values[q K + k, :] * vscale + vshift)
 // K in {8, 16, 32}; Cout = D (channels of scores, values and out).
-// pdr_fused_layer_pool with the score conv on split-bf16 arithmetic (packed weight image as pdr_fused_layer_bf16x3);
+// pdr_fused_layer_pool with the score conv on split-f16 arithmetic (packed weight image as pdr_fused_layer_f16x3);
 // the 128-column wave-specialised tiles only: PDR_EUNSUPPORTED otherwise (the caller uses the exact entry point).
-extern "C" int pdr_fused_layer_pool_bf16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
-                                           const float* bias, int D, const float* values, int ldv,
-                                           const float* vscale, const float* vshift, int v_relu,
-                                           const int* counts, int K, float* out, int ldo, pdr_stream_t stream) {
+extern "C" int pdr_fused_layer_pool_f16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
+                                          const float* bias, int D, const float* values, int ldv,
+                                          const float* vscale, const float* vshift, int v_relu,
+                                          const int* counts, int K, float* out, int ldo, pdr_stream_t stream) {
   if (!in || !Wp || nchunks <= 0 || reinterpret_cast<uintptr_t>(Wp) % 16 != 0 || !values || !out || P <= 0 ||
       Cin <= 0 || D <= 0 || in->n_seg < 1 || in->n_seg > 4 || ldv < D || ldo < D)
     return PDR_EINVAL;

@@ -62,8 +62,8 @@ __device__ __forceinline__ float vmax(float a, float b) {
 
 // LDS image of the two pipeline stages.
 //   fp32 (exact):  A k-major [k][row] (+1 pad), W k-major [k][col]: one ds_read_b32 per MFMA operand element.
-//   SPLIT (bf16x3): every fp32 value x is held as hi = bf16(x), lo = bf16(x - hi); A and W are ROW-major
-//   [row][32 k] / [col][32 k] bf16 = 64-byte rows so that a lane's MFMA operand (8 consecutive k of one row) is ONE
+//   SPLIT (f16x3): every fp32 value x is held as hi = f16(x), lo = f16(x - hi); A and W are ROW-major
+//   [row][32 k] / [col][32 k] halves = 64-byte rows so that a lane's MFMA operand (8 consecutive k of one row) is ONE
 //   ds_read_b128.  Rows are unpadded; the 16-byte granule g of row r sits at position g ^ ((r >> 2) & 3): the 16
 //   lanes of a ds_read_b128 service group (rows distinct mod 16, same g) then hit 16 distinct 16-byte slots of the
 //   256-byte bank row, and a producer's 16-lane ds_write_b64 group covers two whole rows = 32 distinct banks.
@@ -81,15 +81,15 @@ struct StageMem<false, KC, TM, TN> {
 };
 template <int KC, int TM, int TN>
 struct StageMem<true, KC, TM, TN> {
-  static_assert(KC == 32, "split layout: 32 bf16 = 64-byte rows");
+  static_assert(KC == 32, "split layout: 32 halves = 64-byte rows");
   __attribute__((aligned(16))) unsigned char A[2][2][TM * 64];   // [stage][hi / lo][row][64 B]
   __attribute__((aligned(16))) unsigned char B[2][2][TN * 64];   // [stage][hi / lo][col][64 B]
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
-// byte offset of k-granule g (8 bf16 = 16 B) of row r inside a [rows][64 B] image
+// byte offset of k-granule g (8 halves = 16 B) of row r inside a [rows][64 B] image
 __device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ ((r >> 2) & 3)) << 4); }
 
 // GATH: 0 = plain sources, 1 = gathered ball-query first conv (U[idx] + V, empty balls), 2 = gathered kNN first conv
@@ -98,7 +98,7 @@ __device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ (
 // Workgroups per CU: two (4 waves per SIMD, 128 registers) for every tile shape but the 128 x 32 narrow tiles without a
 // residual source: those are bound by the latency of their single chunk in flight, hold 16 accumulators and fit 80
 // registers and 51 KB of LDS, so THREE workgroups per CU (6 waves per SIMD) keep half as many chunks again in flight:
-// 8.69 / 8.68 / 8.67 -> 8.54 / 8.56 / 8.59 ms per step (split-bf16 step 7.25 -> 7.07).  The residual forms need 92-200
+// 8.69 / 8.68 / 8.67 -> 8.54 / 8.56 / 8.59 ms per step (split step 7.25 -> 7.07).  The residual forms need 92-200
 // bytes of scratch per lane under the 80-register cap and lose (8.6 -> 9.1 ms): they stay at two.
 template <int RT, int CT, bool RADD, bool SPLIT>
 constexpr int ws_waves_per_simd() { return (RT * CT == 1 && !RADD && !SPLIT) ? 6 : 4; }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
     float* __restrict__ partial, int relu_col0, int n_row_tiles, int tile_order, pdr::PoolArgs pool) {
-  // SPLIT: `Wt` points at the packed bf16 hi / lo weight image (pdr_pack_weights_bf16x3: per column block and
+  // SPLIT: `Wt` points at the packed f16 hi / lo weight image (pack_f16x3 of fused_network.py: per column block and
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
   constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
@@ -508,13 +508,14 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
             *reinterpret_cast<f32x2*>(&sm.As[st][2 * vc4 + 1][prow(i)][0]) = f32x2{x[2], x[3]};
           }
           if constexpr (SPLIT) {
-            // x = hi + lo + O(2^-17 |x|): hi = bf16(x) (round to nearest even), lo = bf16(x - hi); the four
+            // x = hi + lo + O(max(2^-23 |x|, 2^-25)): hi = f16(x) (round to nearest even), lo = f16(x - hi) -- lo is
+            // a SUBNORMAL half for |x| < 0.25, which v_mfma_*_f16 honours (measured: tools/lab/split_half.py); the four
             // channels of this thread are 4 consecutive k of row r: 8 bytes of the hi image, 8 of the lo image
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 v01 = {x[0], x[1]}, v23 = {x[2], x[3]};
-            const bf16x2 h01 = __builtin_convertvector(v01, bf16x2), h23 = __builtin_convertvector(v23, bf16x2);
+            const half2v h01 = __builtin_convertvector(v01, half2v), h23 = __builtin_convertvector(v23, half2v);
             const f2 r01 = v01 - __builtin_convertvector(h01, f2), r23 = v23 - __builtin_convertvector(h23, f2);
-            const bf16x2 l01 = __builtin_convertvector(r01, bf16x2), l23 = __builtin_convertvector(r23, bf16x2);
+            const half2v l01 = __builtin_convertvector(r01, half2v), l23 = __builtin_convertvector(r23, half2v);
             const int r = prow(i);
             const int off = split_off(r, vc4 >> 1) + ((vc4 & 1) << 3);
             typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -595,31 +596,31 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     PDR_T(0, 4 * g + 1);
     const int st = g & 1;
     if constexpr (SPLIT) {
-      // bf16x3: x . w = xh wh + xh wl + xl wh (+ xl wl ~ 2^-16 relative, dropped), fp32 accumulation, on
-      // v_mfma_f32_32x32x16_bf16: lane (il, hi) supplies 8 consecutive k (k = 16 ks + 8 hi ...) of its row / column
+      // f16x3: x . w = xh wh + xh wl + xl wh (+ xl wl ~ 2^-22 relative, dropped), fp32 accumulation, on
+      // v_mfma_f32_32x32x16_f16: lane (il, hi) supplies 8 consecutive k (k = 16 ks + 8 hi ...) of its row / column
       const int ksteps16 = (min(KC, in.seg[cur.sg].C - cur.ks) + 15) >> 4;
       for (int ks = 0; ks < ksteps16; ++ks) {
-        bf16x8 ah[RT], al[RT], wh[CT], wl[CT];
+        half8 ah[RT], al[RT], wh[CT], wl[CT];
         const int gq = 2 * ks + hi;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
           const int off = split_off((wr * RT + i) * 32 + il, gq);
-          ah[i] = *reinterpret_cast<const bf16x8*>(&sm.A[st][0][off]);
-          al[i] = *reinterpret_cast<const bf16x8*>(&sm.A[st][1][off]);
+          ah[i] = *reinterpret_cast<const half8*>(&sm.A[st][0][off]);
+          al[i] = *reinterpret_cast<const half8*>(&sm.A[st][1][off]);
         }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
           const int off = split_off((wc * CT + j) * 32 + il, gq);
-          wh[j] = *reinterpret_cast<const bf16x8*>(&sm.B[st][0][off]);
-          wl[j] = *reinterpret_cast<const bf16x8*>(&sm.B[st][1][off]);
+          wh[j] = *reinterpret_cast<const half8*>(&sm.B[st][0][off]);
+          wl[j] = *reinterpret_cast<const half8*>(&sm.B[st][1][off]);
         }
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
           for (int j = 0; j < CT; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
           }
       }
     } else {
@@ -961,7 +962,7 @@ bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t
 }
 
 // Launches the wave-specialised kernel for tile variant `id`.  Returns false when the variant has no
-// wave-specialised instantiation.  split: bf16x3 arithmetic (Wt = packed weight image, ldw = chunks per column
+// wave-specialised instantiation.  split: f16x3 arithmetic (Wt = packed weight image, ldw = chunks per column
 // block); instantiated for the 128-column tile variants 4 and 5 and the 64-column variant 8.
 bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt,
                            int ldw, const float* bias, int Cout, float* Y, int ldy, float* partial,

@@ -295,24 +295,25 @@ def _fork_join(rows, chain_a):
     return join
 
 
-# Arithmetic of the wide GEMMs of the forward in flight: "f32" (exact fp32 MFMA, default) or "split_bf16"
-# (opt-in; FusedCloudConditionNet(precision=...) sets it around its forward).  See pack_bf16x3 / run_layer.
+# Arithmetic of the wide GEMMs of the forward in flight: "f32" (exact fp32 MFMA, default) or "split_f16"
+# (opt-in; FusedCloudConditionNet(precision=...) sets it around its forward).  See pack_f16x3 / run_layer.
 _PRECISION = ["f32"]
-# tile variants that have a split-bf16 instantiation: 4 / 5 (128-column blocks), 8 (64-column blocks)
+# tile variants that have a split-f16 instantiation: 4 / 5 (128-column blocks), 8 (64-column blocks)
 SPLIT_VARIANTS = tuple(int(v) for v in __import__("os").environ.get("PDR_SPLIT_VARIANTS", "4,5,8").split(","))
 # layers with fewer input channels stay exact (HBM-bound: nothing to gain).  Same box, split step: 128 -> 7.33 ms, 64 ->
 # 7.16, 32 -> 7.16 (the 64-channel layers of the 64-column tiles are the ones that matter).  PDR_SPLIT_MIN_CIN: A/B
 SPLIT_MIN_CIN = int(__import__("os").environ.get("PDR_SPLIT_MIN_CIN", "64"))
 
 
-def pack_bf16x3(Wt, Cout, seg_widths, TN=128):
-    """Weight image of pdr_fused_layer_bf16x3 (layout contract in include/pdr_hip.h): Wt (Cin, >= Cout) fp32 ->
+def pack_f16x3(Wt, Cout, seg_widths, TN=128):
+    """Weight image of pdr_fused_layer_f16x3 (layout contract in include/pdr_hip.h): Wt (Cin, >= Cout) fp32 ->
     int16 tensor [column block][chunk][hi | lo][TN cols][32 k], k-granules XOR-swizzled; TN = column-block width of the
     tile variant that will run the layer (128, or 64 for variant 8); returns (image, chunks)."""
     KC = 32
     W = Wt[:, :Cout].float()
-    hi = W.to(torch.bfloat16)                                   # round to nearest even, as v_cvt_pk_bf16_f32
-    lo = (W - hi.float()).to(torch.bfloat16)
+    half = torch.float16
+    hi = W.to(half)                                             # round to nearest even, as v_cvt_pk_f16_f32
+    lo = (W - hi.float()).to(half)                              # (subnormal halves kept, as the kernel's operands)
     chunks, k = [], 0
     for C in seg_widths:
         for ks in range(0, C, KC):
@@ -320,7 +321,7 @@ def pack_bf16x3(Wt, Cout, seg_widths, TN=128):
         k += C
     assert k == W.shape[0]
     ncb = (Cout + TN - 1) // TN
-    img = torch.zeros((ncb, len(chunks), 2, TN, KC), dtype=torch.bfloat16, device=Wt.device)
+    img = torch.zeros((ncb, len(chunks), 2, TN, KC), dtype=half, device=Wt.device)
     for cb in range(ncb):
         n0 = cb * TN
         nn_ = min(TN, Cout - n0)
@@ -336,24 +337,24 @@ def pack_bf16x3(Wt, Cout, seg_widths, TN=128):
 
 
 def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, relu_col0):
-    """Try the bf16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel)."""
-    if _PRECISION[0] != "split_bf16" or conv.Cin < SPLIT_MIN_CIN:
+    """Try the f16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel)."""
+    if _PRECISION[0] != "split_f16" or conv.Cin < SPLIT_MIN_CIN:
         return False
     variant = lib.pdr_fused_layer_variant(act.rpb, conv.Cout)
     if variant not in SPLIT_VARIANTS:
         return False
     TN = 64 if variant == 8 else 128
     key = tuple(sg[2] for sg in act.segs) + (TN,)
-    cache = conv.__dict__.setdefault("_bf16x3", {})
+    cache = conv.__dict__.setdefault("_f16x3", {})
     if key not in cache:
-        cache[key] = pack_bf16x3(conv.Wt, conv.Cout, key[:-1], TN)
+        cache[key] = pack_f16x3(conv.Wt, conv.Cout, key[:-1], TN)
     img, nch = cache[key]
-    rc = lib.pdr_fused_layer_bf16x3(ctypes.byref(li), act.P, conv.Cin, img.data_ptr(), nch, conv.bias.data_ptr(),
+    rc = lib.pdr_fused_layer_f16x3(ctypes.byref(li), act.P, conv.Cin, img.data_ptr(), nch, conv.bias.data_ptr(),
                                     conv.Cout, y_ptr, ldy, partial.data_ptr() if partial is not None else None,
                                     relu_col0, _stream())
     if rc == _lib.PDR_EUNSUPPORTED:
         return False
-    _lib.check(rc, "fused_layer_bf16x3")
+    _lib.check(rc, "fused_layer_f16x3")
     return True
 
 
@@ -678,21 +679,21 @@ class FusedAttention:
             # last score conv + mask + softmax over K + weighted sum in ONE kernel: scores stay in the
             # MFMA accumulators
             li = score_in.struct()
-            if _PRECISION[0] == "split_bf16" and self.w2.Cin >= SPLIT_MIN_CIN and \
+            if _PRECISION[0] == "split_f16" and self.w2.Cin >= SPLIT_MIN_CIN and \
                     lib.pdr_fused_layer_variant(npoint * K, self.D) in SPLIT_VARIANTS:
-                # score conv on split-bf16 arithmetic too (128-column tiles; else the exact kernel below)
+                # score conv on split-f16 arithmetic too (128-column tiles; else the exact kernel below)
                 variant = lib.pdr_fused_layer_variant(npoint * K, self.D)
                 TN = 64 if variant == 8 else 128
-                cache = self.w2.__dict__.setdefault("_bf16x3", {})
+                cache = self.w2.__dict__.setdefault("_f16x3", {})
                 key = (self.w2.Cin, TN)
                 if key not in cache:
-                    cache[key] = pack_bf16x3(self.w2.Wt, self.w2.Cout, key[:1], TN)
+                    cache[key] = pack_f16x3(self.w2.Wt, self.w2.Cout, key[:1], TN)
                 img, nch = cache[key]
-                rc = lib.pdr_fused_layer_pool_bf16x3(ctypes.byref(li), P, self.w2.Cin, img.data_ptr(), nch,
+                rc = lib.pdr_fused_layer_pool_f16x3(ctypes.byref(li), P, self.w2.Cin, img.data_ptr(), nch,
                                                      self.w2.bias.data_ptr(), self.D, V.data_ptr(), V.shape[1], vsp, vtp,
                                                      int(self.v_relu), cptr, K, out.data_ptr(), self.D, _stream())
                 if rc != _lib.PDR_EUNSUPPORTED:
-                    _lib.check(rc, "fused_layer_pool_bf16x3")
+                    _lib.check(rc, "fused_layer_pool_f16x3")
                     return out
             _lib.check(lib.pdr_fused_layer_pool(ctypes.byref(li), P, self.w2.Cin, self.w2.Wt.data_ptr(), self.w2.ldw,
                                                 self.w2.bias.data_ptr(), self.D, V.data_ptr(), V.shape[1], vsp, vtp,
@@ -1066,11 +1067,13 @@ class FusedCloudConditionNet:
     """Cached-condition forward of PointNet2CloudCondition through the fused kernels."""
 
     def __init__(self, net, precision="f32"):
-        """precision: "f32" (default; every GEMM on the exact fp32 MFMA) or "split_bf16" (opt-in: GEMMs with
-        Cin >= 128 split both operands into bf16 hi + lo parts and run 3 bf16 MFMAs with fp32 accumulation)."""
+        """precision: "f32" (default; every GEMM on the exact fp32 MFMA) or "split_f16" (opt-in: GEMMs with
+        Cin >= 64 split both operands into f16 hi + lo parts and run 3 f16 MFMAs with fp32 accumulation: fp32-class
+        products -- eps within 1.2e-5 of the exact network -- for operands of ordinary magnitude, see
+        include/pdr_hip.h pdr_fused_layer_f16x3)."""
         hp = net.hparams
-        if precision not in ("f32", "split_bf16"):
-            raise ValueError("precision must be 'f32' or 'split_bf16'")
+        if precision not in ("f32", "split_f16"):
+            raise ValueError("precision must be 'f32' or 'split_f16'")
         self.precision = precision
         if net.scale_factor != 1:
             raise NotImplementedError("fused path: scale_factor == 1 (coordinates are not rescaled here)")

@@ -733,16 +733,17 @@ def test_attention_pool_matches_masked_softmax(cuda, B, npoint, K, D, ld, use_co
     assert _rel(out.double(), want) < 2e-6
 
 
-# ------------------------------------------------------------------ split-bf16 (opt-in) arithmetic
+# ------------------------------------------------------------------ split-f16 (opt-in) arithmetic
 @pytest.mark.parametrize("P,Cin,Cout,rpb,segs", [(1024, 128, 128, 256, (128,)), (2048, 331, 331, 1024, (171, 160)),
                                                  (512, 512, 512, 64, (512,)), (4096, 203, 128, 4096, (200, 3)),
                                                  (1 << 16, 256, 256, 8192, (128, 128)),
                                                  (4096, 256, 64, 1024, (256,)), (2048, 140, 64, 256, (128, 12))])
-def test_split_bf16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch):
-    """pdr_fused_layer_bf16x3 (x . w = xh wh + xh wl + xl wh on bf16 MFMA, fp32 accumulate): every element within
-    1e-4 of the float64 result RELATIVE TO THE ROW's |x| . |w| scale (the exact fp32 kernel sits at ~1e-6), incl.
-    multi-segment inputs, a partial last chunk, the prologue and a residual; statistics as in the exact kernel.
-    The last two shapes run on the 64-column tile variant (64-column weight image)."""
+def test_split_f16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch):
+    """pdr_fused_layer_f16x3 (x . w = xh wh + xh wl + xl wh on f16 MFMA, fp32 accumulate; both operands held as two
+    11-bit halves): every element within 2e-6 of the float64 result RELATIVE TO THE ROW's |x| . |w| scale -- the bar of
+    the exact fp32 kernel (measured: 2.6e-7 vs 3.7e-7 exact) -- incl. multi-segment inputs, a partial last chunk, the
+    prologue and a residual; statistics as in the exact kernel.  The last two shapes run on the 64-column tile
+    variant (64-column weight image)."""
     g = torch.Generator().manual_seed(Cin * 3 + Cout)
     B = P // rpb
     xs, off = [], 0
@@ -762,7 +763,7 @@ def test_split_bf16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch)
     xin = (x * scale[bidx] + shift[bidx]).relu() + add[bidx]
     ref = xin.double() @ W.t().double() + bias.double()
     bound = (xin.abs().double() @ W.t().abs().double()) + 1.0
-    monkeypatch.setattr(FN, "_PRECISION", ["split_bf16"])
+    monkeypatch.setattr(FN, "_PRECISION", ["split_f16"])
     lib = _lib.load()
     Y = torch.empty((P, FN._ldy(Cout)), device=cuda)
     tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
@@ -770,35 +771,61 @@ def test_split_bf16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch)
     part = torch.empty((B * tpb, Cout, 2), device=cuda)
     assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), "split path not taken"
     err = ((Y[:, :Cout].double() - ref).abs() / bound)
-    assert float(err.max()) < 1e-4, float(err.max())
+    assert float(err.max()) < 2e-6, float(err.max())
     got = part.view(B, tpb, Cout, 2).double().sum(1)
     # (sums over rpb rows cancel: judge them against the sum of magnitudes)
     scale_sum = ref.abs().view(B, rpb, Cout).sum(1) + 1.0
-    assert float(((got[..., 0] - ref.view(B, rpb, Cout).sum(1)).abs() / scale_sum).max()) < 1e-4
+    assert float(((got[..., 0] - ref.view(B, rpb, Cout).sum(1)).abs() / scale_sum).max()) < 1e-5
     assert float(((got[..., 1] - (ref * ref).view(B, rpb, Cout).sum(1)).abs() /
-                  ((ref * ref).view(B, rpb, Cout).sum(1) + 1.0)).max()) < 1e-4
-    # and the exact kernel on the same input is (much) closer: the mode really changes the arithmetic
+                  ((ref * ref).view(B, rpb, Cout).sum(1) + 1.0)).max()) < 1e-5
+    # the mode really changes the arithmetic: not the bytes of the exact kernel, which meets the same bar
     monkeypatch.setattr(FN, "_PRECISION", ["f32"])
     Ye, _, _ = FN.run_layer(act, conv, stats=True)
     exact = ((Ye[:, :Cout].double() - ref).abs() / bound)
-    assert float(exact.max()) < 2e-6 and float(err.max()) > float(exact.max())
+    assert float(exact.max()) < 2e-6 and not torch.equal(Ye[:, :Cout], Y[:, :Cout])
 
 
-def test_split_bf16_network_and_sampler(cuda):
-    """Opt-in precision='split_bf16' on the shipped DDPM architecture: eps vs the exact fused network within the
-    network-level bar, and the graph-captured sampler vs the reference-style loop under the same thresholds as the
-    exact mode (test_fused_network_ddpm_config_and_graphed_sampler)."""
+@pytest.mark.parametrize("magnitude,bar", [(1.0, 1e-6), (1e-2, 4e-6), (1e-4, 4e-4)])
+def test_split_f16_representation_floor(cuda, magnitude, bar, monkeypatch):
+    """The documented contract of the f16 hi + lo representation (include/pdr_hip.h): an operand is held to
+    max(2^-23 |x|, 2^-25).  Inputs of rms 1 and 1e-2 (lo parts subnormal halves, which the MFMA honours) stay at the
+    fp32 class (measured 2.6e-7 / 9.3e-7); at rms 1e-4 the absolute floor shows (1.0e-4) -- the reason the mode is
+    opt-in and fed GroupNorm outputs, coordinates and embeddings only."""
+    P, Cin, Cout, rpb = 1 << 14, 256, 256, 4096
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(P, Cin, generator=g) * magnitude).to(cuda)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    conv = _conv(W, torch.zeros(Cout, device=cuda))
+    act = FN.Act([(x, 0, Cin, Cin, 1)], P, P // rpb, rpb)
+    ref = x.double() @ W.t().double()
+    bound = x.abs().double() @ W.t().abs().double()
+    monkeypatch.setattr(FN, "_PRECISION", ["split_f16"])
+    lib = _lib.load()
+    Y = torch.empty((P, FN._ldy(Cout)), device=cuda)
+    tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+    part = torch.empty(((P // rpb) * ((rpb + tm - 1) // tm), Cout, 2), device=cuda)
+    assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), "split path not taken"
+    err = float(((Y[:, :Cout].double() - ref).abs() / bound).max())
+    assert err < bar, err
+
+
+def test_split_f16_network_and_sampler(cuda):
+    """Opt-in precision='split_f16' on the shipped DDPM architecture: eps vs the exact fused network and vs the
+    layer-by-layer network at north_star's 1e-4 (|d| / max(|want|, rms); measured 1.2e-5 max, 1.2e-6 median -- the
+    exact fused network sits at 6.7e-6 / 6.8e-7 from the layer-by-layer one), and the graph-captured sampler vs the
+    reference-style loop under the same thresholds as the exact mode
+    (test_fused_network_ddpm_config_and_graphed_sampler)."""
+    from tests import parity
     torch.manual_seed(0)
     net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
     exact = FN.FusedCloudConditionNet(net)
-    split = FN.FusedCloudConditionNet(net, precision="split_bf16")
+    split = FN.FusedCloudConditionNet(net, precision="split_f16")
     x, cond, label = synthetic_batch(2, seed=3, device=cuda)
     ts = torch.tensor([500.0, 20.0], device=cuda)
     a, ref = _cached_eps(net, exact, x, cond, ts, label)
     b, _ = _cached_eps(net, split, x, cond, ts, label)
-    for got, want in ((b, a), (b, ref)):
-        err = ((got - want).abs() / (want.abs() + 1.0))
-        assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
+    parity.check("split_f16:eps_vs_exact_fused", "hip", b, a, 1e-4)
+    parity.check("split_f16:eps_vs_layer_by_layer", "hip", b, ref, 1e-4)
     assert float((a - b).abs().max()) > 0.0                               # the split kernels really ran
     dh = util.calc_diffusion_hyperparams(6, 1e-4, 0.02)
     util.set_device(cuda)
@@ -811,6 +838,6 @@ def test_split_bf16_network_and_sampler(cuda):
     torch.manual_seed(77)
     got = GraphedReverseSampler(split, dh, noise='cpu', use_graph=True).sample((2, 2048, 3), cond, label)
     per_cloud = ((got - want).abs() / (want.abs() + 1.0)).flatten(1)
-    # measured: one cloud at 2e-4 (a flipped near-tie, as in the exact mode's longer runs), the other at 4e-7
-    assert (per_cloud.median(1).values < 2e-3).all(), per_cloud.median(1).values
-    assert float(per_cloud.max()) < 0.5, per_cloud.max(1).values
+    # measured medians 6.5e-7 / 4.9e-6 (the second cloud carries a flipped near-tie, as clouds of the exact mode do)
+    assert (per_cloud.median(1).values < 1e-4).all(), per_cloud.median(1).values
+    assert int((per_cloud.max(1).values < 1e-3).sum()) >= 1 and float(per_cloud.max()) < 0.5, per_cloud.max(1).values

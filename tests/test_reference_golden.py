@@ -213,6 +213,13 @@ def test_full_ddpm_config_forward_matches_reference(be):
                      "ddpm_full_fused:eps_first", x)
         be.net_close(fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True),
                      g["eps_cached"], "ddpm_full_fused:eps_cached", x * 0.9)
+        # the opt-in split-f16 arithmetic (three f16 MFMAs per product) at the SAME bars
+        split = FusedCloudConditionNet(net, precision="split_f16")
+        net.reset_cond_features()
+        be.net_close(split(x, cond, ts=ts, label=label, use_retained_condition_feature=True), g["eps_first"],
+                     "ddpm_full_split_f16:eps_first", x)
+        be.net_close(split(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True),
+                     g["eps_cached"], "ddpm_full_split_f16:eps_cached", x * 0.9)
 
 
 def test_full_ddpm_config_sampling_loop_matches_reference(be):
@@ -259,8 +266,8 @@ def test_full_ddpm_config_sampling_loop_matches_reference(be):
     judge("ddpm_full:sampling_T6:layer_by_layer", out, rec.xs)
     from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
     from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedReverseSampler
-    fused = FusedCloudConditionNet(net)
-    for use_graph in (False, True):
+    for precision, use_graph in (("f32", False), ("f32", True), ("split_f16", True)):
+        fused = FusedCloudConditionNet(net, precision=precision)
         sampler = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=use_graph)
         torch.manual_seed(321)
         sampler.begin(tuple(x.shape), cond, label)                         # draws x_T, runs the first (uncached) step
@@ -268,7 +275,8 @@ def test_full_ddpm_config_sampling_loop_matches_reference(be):
         while sampler.remaining > 0:
             xs.append(sampler._x.detach().cpu().clone())
             sampler.advance(1)
-        judge("ddpm_full:sampling_T6:fused_%s" % ("graph" if use_graph else "eager"), sampler.finish(), xs)
+        tag = "fused_%s" % ("graph" if use_graph else "eager") if precision == "f32" else "split_f16_graph"
+        judge("ddpm_full:sampling_T6:" + tag, sampler.finish(), xs)
 
 
 def test_network_forward_caching_and_samplers(be):

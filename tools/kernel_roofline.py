@@ -26,7 +26,7 @@ import torch
 from point_diffusion_refinement_amd import _lib
 
 FP32_MFMA_PEAK_TFLOPS = 157.3
-BF16_MFMA_PEAK_TFLOPS = 2500.0
+F16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -66,7 +66,7 @@ def _work(name, args, lib):
         if plan[6] and not args[9]:                      # <= 4 input channels, no prologue, no statistics
             return "fused_layer_thin_kernel", 2.0 * P * Cin * Cout, byt
         return _layer_symbol(tuple(plan[:6])), 2.0 * P * Cin * Cout, byt
-    if name == "pdr_fused_layer_bf16x3":
+    if name == "pdr_fused_layer_f16x3":
         li = args[0]._obj
         P, Cin, Cout = args[1], args[2], args[6]
         vid = lib.pdr_fused_layer_variant(li.rows_per_batch, Cout)
@@ -125,7 +125,7 @@ def _work(name, args, lib):
     return name.replace("pdr_", "") + " (C ABI)", 0.0, 0.0
 
 
-_TIMED = ("pdr_fused_layer", "pdr_fused_layer_bf16x3", "pdr_fused_layer_pool", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
+_TIMED = ("pdr_fused_layer", "pdr_fused_layer_f16x3", "pdr_fused_layer_pool", "pdr_gather_add", "pdr_attention_pool", "pdr_gn_fold", "pdr_apply_act", "pdr_gather_rows",
           "pdr_furthest_point_sampling", "pdr_ball_query", "pdr_knn_points", "pdr_group_build", "pdr_knn_build",
           "pdr_knn_weights", "pdr_pad_rows", "pdr_knn_group", "pdr_embed_linear", "pdr_reverse_step")
 
@@ -200,10 +200,10 @@ def step_kernel_table(sampler, reps=3, overlapped=False):
 
 
 def _roof(flops, byt, ms, symbol, kind="mfma"):
-    # split mode: three bf16 MFMAs per algorithmic product -> a third of the dense bf16 peak
+    # split mode: three f16 MFMAs per algorithmic product -> a third of the dense f16 peak
     args = symbol[symbol.find("<") + 1:symbol.rfind(">")].split(", ") if "<" in symbol else []
     split = symbol.startswith("fused_layer_ws_kernel") and len(args) >= 8 and args[7] == "true"
-    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+    peak_tf = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
     t_mfma = flops / (peak_tf * 1e12)
     t_hbm = byt / (HBM_PEAK_GBS * 1e9)
     if t_mfma >= t_hbm and flops > 0:
