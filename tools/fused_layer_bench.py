@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--first", type=int, default=0, help="skip SHAPES before this index")
     ap.add_argument("--gath", type=int, default=0, help="K > 0: the source is a gathered first conv (U[idx] + V, K "
                                                          "neighbours per query, 2048 source points per cloud)")
+    ap.add_argument("--split", action="store_true", help="pdr_fused_layer_f16x3 (split-f16 arithmetic) where a tile "
+                                                        "variant carries it")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = args.lib
@@ -71,9 +73,20 @@ def main():
         li.scale, li.shift = scale.data_ptr(), shift.data_ptr()
         li.pre_relu, li.post_relu, li.rows_per_batch = 0, 1, rpb
 
+        variant = lib.pdr_fused_layer_variant(rpb, Cout)
+        split = args.split and variant in (4, 5, 8)
+        if split:
+            from point_diffusion_refinement_amd.pointnet2.fused_network import pack_f16x3
+            img, nchunks = pack_f16x3(Wt, Cout, (Cin,), 64 if variant == 8 else 128)
+
         def call():
-            _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout,
-                                           Y.data_ptr(), ldw, partial.data_ptr(), Cout, st), "fused_layer")
+            if split:
+                _lib.check(lib.pdr_fused_layer_f16x3(ctypes.byref(li), P, Cin, img.data_ptr(), nchunks, bias.data_ptr(),
+                                                     Cout, Y.data_ptr(), ldw, partial.data_ptr(), Cout, st),
+                           "fused_layer_f16x3")
+            else:
+                _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout,
+                                               Y.data_ptr(), ldw, partial.data_ptr(), Cout, st), "fused_layer")
         for _ in range(3):
             call()
         torch.cuda.synchronize()
@@ -87,8 +100,8 @@ def main():
         tot += us
         tf = 2.0 * P * Cin * Cout / us / 1e6
         gb = 4.0 * P * (Cin + Cout) / us / 1e3
-        print("rpb=%6d Cin=%4d Cout=%4d variant=%d: %8.1f us %6.1f TF %6.0f GB/s" %
-              (rpb, Cin, Cout, lib.pdr_fused_layer_variant(rpb, Cout), us, tf, gb))
+        print("rpb=%6d Cin=%4d Cout=%4d variant=%d%s: %8.1f us %6.1f TF %6.0f GB/s" %
+              (rpb, Cin, Cout, variant, " split" if split else "", us, tf, gb))
     print("total %.1f us" % tot)
 
 
