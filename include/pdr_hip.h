@@ -33,9 +33,10 @@
  *     pdr_furthest_point_sampling), PDR_KNN_WAVE=0 (thread-per-query instead of
  *     wave-per-query kNN for K <= 8), PDR_GN_FOLD_SMALL=0 (1024-thread
  *     GroupNorm fold workgroups), PDR_WS_NARROW3=0 (two instead of three
- *     co-resident workgroups per CU for the 128 x 32 tiles) and
+ *     co-resident workgroups per CU for the 128 x 32 tiles),
  *     PDR_WS_XCD_ORDER=1|2 (XCD-local tile order of the gathered / of all layer
- *     kernels instead of the plain one).
+ *     kernels instead of the plain one) and PDR_WS_RESIDENT_PCT=10..100 (launch
+ *     that share of a layer kernel's co-resident workgroups; lab knob).
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined
  *     behaviour, as in the reference's kernels).

@@ -979,7 +979,15 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     const char* e = getenv("PDR_WS_NARROW3");
     return !(e && e[0] == '0');
   }();
-  const long resident = (narrow3 && id == 7 && !radd && !split) ? 768 : 512;
+  // PDR_WS_RESIDENT_PCT (lab knob, default 100): percentage of the co-resident workgroup count actually launched --
+  // 50 = one layer workgroup per CU, so that the kernels of the two block-half streams share every CU instead of
+  // taking turns on the chip
+  static const long resident_pct = [] {
+    const char* e = getenv("PDR_WS_RESIDENT_PCT");
+    const long v = e ? atol(e) : 100;
+    return v >= 10 && v <= 100 ? v : 100;
+  }();
+  const long resident = ((narrow3 && id == 7 && !radd && !split) ? 768 : 512) * resident_pct / 100;
   // PDR_WS_XCD_ORDER: 1 = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer, 0 (default)
   // = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
   // (143 MB algorithmic), of the kNN-gathered narrow tiles 178 -> 143 MB, ball-gathered kernels unchanged; step time
