@@ -34,8 +34,8 @@
  *     wave-per-query kNN for K <= 8), PDR_GN_FOLD_SMALL=0 (1024-thread
  *     GroupNorm fold workgroups), PDR_WS_NARROW3=0 (two instead of three
  *     co-resident workgroups per CU for the 128 x 32 tiles),
- *     PDR_WS_XCD_ORDER=1|2 (XCD-local tile order of the gathered / of all layer
- *     kernels instead of the plain one) and PDR_WS_RESIDENT_PCT=10..100 (launch
+ *     PDR_WS_XCD_ORDER=0|2 (plain tile order for every layer kernel / XCD-local
+ *     order for all of them; default 1 = XCD-local for the gathered ones) and PDR_WS_RESIDENT_PCT=10..100 (launch
  *     that share of a layer kernel's co-resident workgroups; lab knob).
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined

@@ -988,15 +988,17 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     return v >= 10 && v <= 100 ? v : 100;
   }();
   const long resident = ((narrow3 && id == 7 && !radd && !split) ? 768 : 512) * resident_pct / 100;
-  // PDR_WS_XCD_ORDER: 1 = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer, 0 (default)
-  // = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
+  // PDR_WS_XCD_ORDER: 1 (default) = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer,
+  // 0 = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
   // (143 MB algorithmic), of the kNN-gathered narrow tiles 178 -> 143 MB, ball-gathered kernels unchanged; step time
-  // 8.75 / 8.75 / 8.76 (plain) vs 8.79 / 8.69 / 8.78 (gathered kernels) vs 8.80 / 8.80 / 8.79 (all); the dominant
-  // kernel alone on the chip 149.3 / 149.3 us (plain) vs 152.3 / 149.8 us: fewer bytes, no time gained (MFMA-bound),
-  // so the plain order stays the default.  Results are bit-identical (tools/lab/order_check.py, tests).
+  // 8.75 / 8.75 / 8.76 (plain) vs 8.79 / 8.69 / 8.78 (gathered kernels) vs 8.80 / 8.80 / 8.79 (all), and again at the
+  // end of round 3 8.78 / 8.82 / 8.75 vs 8.72 / 8.82 / 8.76 (split-f16: 7.36 / 7.39 / 7.35 vs 7.31 / 7.40 / 7.38); the
+  // dominant kernel alone on the chip 149.3 / 149.3 us (plain) vs 152.3 / 149.8 us: a fifth fewer bytes at the same
+  // time (the kernels are MFMA-bound), which is why the gathered kernels take it by default and the others do not.
+  // Results are bit-identical (tools/lab/order_check.py, tests).
   static const int xcd_knob = [] {
     const char* e = getenv("PDR_WS_XCD_ORDER");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 1;
   }();
   const int tile_order = (xcd_knob >= 2 || (xcd_knob == 1 && gath)) ? 1 : 0;
   long cap = (resident + ncol - 1) / ncol;
