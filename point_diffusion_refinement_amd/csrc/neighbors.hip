@@ -137,27 +137,61 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   const float* c = cloud + static_cast<size_t>(b) * nc * 3;
   const float* q = queries + static_cast<size_t>(b) * nq * 3;
   float px[NCH], py[NCH], pz[NCH];
+  // (unconditional loads from a clamped slot, all in flight together; a load under `k < nc` is a branch with its
+  // own wait: 16 dependent round trips before the first query)
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    const int k = ch * 64 + lane;
-    const bool ok = k < nc;
+    const int k = min(ch * 64 + lane, nc - 1);
+    px[ch] = c[k * 3 + 0];
+    py[ch] = c[k * 3 + 1];
+    pz[ch] = c[k * 3 + 2];
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
     // out-of-range slots: +inf -> d = +inf, behind every real point
-    px[ch] = ok ? c[k * 3 + 0] : __builtin_inff();
-    py[ch] = ok ? c[k * 3 + 1] : __builtin_inff();
-    pz[ch] = ok ? c[k * 3 + 2] : __builtin_inff();
+    const bool ok = ch * 64 + lane < nc;
+    px[ch] = ok ? px[ch] : __builtin_inff();
+    py[ch] = ok ? py[ch] : __builtin_inff();
+    pz[ch] = ok ? pz[ch] : __builtin_inff();
   }
   const int j0 = (blockIdx.x * 4 + wave) * qpw;
+  // The cloud slots are complete BEFORE the query loop: without this the wait-count pass puts the vmcnt(0) of their
+  // first use inside the loop, where (stores count in vmcnt on gfx9) it also drains the previous query's stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  // query coordinates one trip ahead (scalar loads: their latency was exposed at the top of every trip)
+  const int jf = min(j0, nq - 1);
+  float nqx = q[jf * 3 + 0], nqy = q[jf * 3 + 1], nqz = q[jf * 3 + 2];
   for (int jj = 0; jj < qpw; ++jj) {
     const int j = j0 + jj;   // wave-uniform
     if (j >= nq) break;
-    const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+    const float qx = nqx, qy = nqy, qz = nqz;
+    {
+      const int jn = min(j + 1, nq - 1);
+      nqx = q[jn * 3 + 0], nqy = q[jn * 3 + 1], nqz = q[jn * 3 + 2];
+    }
     float d[NCH];
     float m = __builtin_inff();
+    if constexpr (NCH % 2 == 0) {
+      // two cloud slots per instruction: v_pk_add / v_pk_mul / v_pk_fma evaluate PDR_ACC3 on a pair of points with
+      // the same roundings as the scalar form (a packed fma IS two fmas), one v_min3 folds the pair into the minimum
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const float dx = qx - px[ch], dy = qy - py[ch], dz = qz - pz[ch];
-      d[ch] = PDR_ACC3(dx, dy, dz);
-      m = fminf(m, d[ch]);
+      for (int ch = 0; ch < NCH; ch += 2) {
+        const f2 dx = qx2 - f2{px[ch], px[ch + 1]}, dy = qy2 - f2{py[ch], py[ch + 1]},
+                 dz = qz2 - f2{pz[ch], pz[ch + 1]};
+        const f2 dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        d[ch] = dd.x;
+        d[ch + 1] = dd.y;
+        m = fminf(m, fminf(dd.x, dd.y));
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const float dx = qx - px[ch], dy = qy - py[ch], dz = qz - pz[ch];
+        d[ch] = PDR_ACC3(dx, dy, dz);
+        m = fminf(m, d[ch]);
+      }
     }
     // minimum of each aligned group of 8 lanes (xor 1, xor 2 inside a quad, then the other quad of the half row),
     // then the maximum over the wave as unsigned bits (distances are >= 0: bit order == value order)
