@@ -658,16 +658,19 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(FoldPart p0, FoldPart p1, 
     const long stride = static_cast<long>(p.ldp) * 2;
     const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + col) * 2;
     for (int t = sl; t < p.tiles_per_batch; t += 32) {
+      // four loads in flight: unconditional, from a clamped tile (t itself is valid), zeroed afterwards -- a load
+      // under `tt < tiles` compiles to a branch with its own vmcnt(0), i.e. four dependent round trips per trip
       float2 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int tt = t + 8 * u;
-        v[u] = tt < p.tiles_per_batch ? *reinterpret_cast<const float2*>(q + tt * stride) : make_float2(0.0f, 0.0f);
+        v[u] = *reinterpret_cast<const float2*>(q + (tt < p.tiles_per_batch ? tt : t) * stride);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        s1 += v[u].x;
-        s2 += v[u].y;
+        const bool ok = t + 8 * u < p.tiles_per_batch;
+        s1 += ok ? v[u].x : 0.0f;
+        s2 += ok ? v[u].y : 0.0f;
       }
     }
   }
@@ -785,11 +788,19 @@ __global__ __launch_bounds__(256) void fused_layer_thin_kernel(const float* __re
 #pragma unroll
   for (int j = 0; j < 4; ++j) b4[j] = (bias && c0 + j < Cout) ? bias[c0 + j] : 0.0f;
   const long r0 = static_cast<long>(blockIdx.x) * (rpp * kThinIters) + rl;
+  // all eight row loads in flight before the first store (a load inside `if (row < P)` waits for itself AND -- stores
+  // count in vmcnt on gfx9 -- for the previous trip's store: eight dependent round trips per workgroup)
+  float4 xr[kThinIters];
+#pragma unroll
+  for (int it = 0; it < kThinIters; ++it) {
+    const long row = r0 + static_cast<long>(it) * rpp;
+    xr[it] = *reinterpret_cast<const float4*>(X + ((row < P ? row : P - 1) >> shift) * ldx);
+  }
 #pragma unroll
   for (int it = 0; it < kThinIters; ++it) {
     const long row = r0 + static_cast<long>(it) * rpp;
     if (row < P) {
-      const float4 x = *reinterpret_cast<const float4*>(X + (row >> shift) * ldx);
+      const float4 x = xr[it];
       const float xs[4] = {x.x, x.y, x.z, x.w};
       float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
       // channel order 0, 2, 1, 3: the tile kernels' first MFMA of a channel quad multiplies the pair (0, 2), the
