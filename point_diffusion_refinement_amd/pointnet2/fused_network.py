@@ -75,7 +75,9 @@ GATHER_RES_KNN = __import__("os").environ.get("PDR_GATHER_RES_KNN", "1") == "1" 
 # Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
 # 11.57 ms issued ahead of the fork (B = 8: 5.82 vs 5.92) -- the later start of the FPS chain costs more than the
 # embedding launches save -- so the default stays OFF; the rocprofv3 timeline that suggested the opposite turned
-# out to be distorted by the tracer.
+# out to be distorted by the tracer.  Re-measured at the end of round 3 (three native embedding launches instead of ~12
+# torch ones; the untraced markers put `embeddings_done` at 260 us, the first ball query at 104 us): 8.79 / 8.82 / 8.83
+# ahead of the fork vs 8.77 / 8.79 / 8.80 beside it -- still not a gain.
 EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
 # Geometry prepass: one event per level instead of one after the whole chain (see _forward_cached).
 # PDR_LEVEL_EVENTS=0 restores the single wait (A/B).
