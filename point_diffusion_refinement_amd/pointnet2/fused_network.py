@@ -1401,6 +1401,7 @@ class FusedCloudConditionNet:
         # ---- embeddings (A/B: PDR_EARLY_EMBED=0 issues them here, beside the running geometry stream)
         # (measured and dropped in round 3: the first ball query on the main stream with the FPS chain opening the
         # geometry stream -- 8.81 / 8.79 / 8.82 vs 8.78 / 8.80 / 8.83 ms per step, no difference)
+        mark("main:before_embeddings", detail=True)
         if not early:
             self._embeddings(ts, label)
         mark("main:embeddings_done")
