@@ -315,6 +315,10 @@ def pack_f16x3(Wt, Cout, seg_widths, TN=128):
     W = Wt[:, :Cout].float()
     half = torch.float16
     hi = W.to(half)                                             # round to nearest even, as v_cvt_pk_f16_f32
+    # (packed once per layer, before any graph capture: the check may synchronise)
+    if not bool(torch.isfinite(hi).all()):
+        raise ValueError("split-f16 arithmetic: a weight is not finite or exceeds the f16 range (65504); use "
+                         "precision='f32' for this network")
     lo = (W - hi.float()).to(half)                              # (subnormal halves kept, as the kernel's operands)
     chunks, k = [], 0
     for C in seg_widths:

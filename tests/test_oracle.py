@@ -277,3 +277,4 @@ def test_discrete_decision_replay_detects_a_flip_and_only_there():
     with pytest.raises(AssertionError):
         parity.check("unit_fail", "cpu", want + 1e-2, want, 1e-4)
     del parity.RECORDS[n0:]                                          # keep the session's parity dump clean
+
