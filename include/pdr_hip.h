@@ -35,8 +35,9 @@
  *     GroupNorm fold workgroups), PDR_WS_NARROW3=0 (two instead of three
  *     co-resident workgroups per CU for the 128 x 32 tiles),
  *     PDR_WS_XCD_ORDER=0|2 (plain tile order for every layer kernel / XCD-local
- *     order for all of them; default 1 = XCD-local for the gathered ones) and PDR_WS_RESIDENT_PCT=10..100 (launch
- *     that share of a layer kernel's co-resident workgroups; lab knob).
+ *     order for all of them; default 1 = XCD-local for the gathered ones).
+ *     tests/test_fused_gpu.py::test_ddpm_forward_with_every_non_default_variant runs
+ *     the full DDPM forward under each of them.
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
  *     (an out-of-range index in a caller-provided idx array is undefined
  *     behaviour, as in the reference's kernels).
@@ -273,8 +274,13 @@ int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, 
  * with xh = f16(x), xl = f16(x - xh) (same for w) on v_mfma_f32_32x32x16_f16, fp32 accumulation: every operand is
  * held to max(2^-23 |x|, 2^-25) (two 11-bit halves; the MFMA honours the subnormal lo parts), the dropped xl wl term
  * is 2^-22 relative -- fp32-class products at 3/16 of the fp32 MFMA cycles, PROVIDED the operands are of ordinary
- * magnitude: |x| < 65504 after the prologue, and inputs whose rms is below ~1e-3 lose relative accuracy to the
- * 2^-25 absolute floor (the fused network feeds these layers GroupNorm outputs, coordinates and embeddings).
+ * magnitude.  RANGE CONTRACT of the activations (after the prologue): the conversions run with MODE.FP16_OVFL = 1,
+ * so an overflowing half saturates at +-65504 instead of becoming inf: |x| <= 131008 is represented as
+ * hi = +-65504 + lo like any other value (relative error <= 2^-11 * 65504 / |x| above 65504, i.e. still 2^-12);
+ * beyond 131008 both halves SATURATE and the product is silently that of the clamped operand -- finite, never NaN
+ * (before round 4 |x| > 65504 produced inf - inf = NaN).  Weights outside the f16 range are refused when the
+ * image is packed.  Inputs whose rms is below ~1e-3 lose relative accuracy to the 2^-25 absolute floor (the fused
+ * network feeds these layers GroupNorm outputs, coordinates, embeddings and first-conv sums of O(1-100)).
  * `Wp`: the weights packed by the caller, 16-byte aligned: for every column block cb (128 columns; 64 for tile
  * variant 8) and every K-chunk c (the input segments in order, each cut into chunks of 32 channels, the
  * last one zero-padded) one block  [hi | lo] x [columns][32 k] halves (k contiguous, 64-byte rows) whose

@@ -191,6 +191,15 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
 #ifndef PDR_LAB_NO_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
+    if constexpr (SPLIT) {
+      // MODE.FP16_OVFL (hwreg 1, bit 23) = 1 in the producer waves: an f32 -> f16 conversion that overflows returns
+      // +-65504 instead of +-inf.  Activations here have passed a GroupNorm (O(1)), but the gathered first-conv sums,
+      // source tables and the head's input are un-normalised: with the default mode |x| > 65504 gave hi = inf,
+      // lo = f16(x - inf) = -inf and NaN products.  With the clamp hi = 65504 and lo = f16(x - 65504)
+      // carry |x| <= 131008 like any other value; beyond that both halves saturate (finite, documented in
+      // include/pdr_hip.h) -- no instruction is added to the staging path.
+      __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    }
     const float lo_pre = in.pre_relu ? 0.0f : -__builtin_inff();
     const float lo_post = in.post_relu ? 0.0f : -__builtin_inff();
     const int pt = tid - 256;
@@ -979,15 +988,9 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
     const char* e = getenv("PDR_WS_NARROW3");
     return !(e && e[0] == '0');
   }();
-  // PDR_WS_RESIDENT_PCT (lab knob, default 100): percentage of the co-resident workgroup count actually launched --
-  // 50 = one layer workgroup per CU, so that the kernels of the two block-half streams share every CU instead of
-  // taking turns on the chip
-  static const long resident_pct = [] {
-    const char* e = getenv("PDR_WS_RESIDENT_PCT");
-    const long v = e ? atol(e) : 100;
-    return v >= 10 && v <= 100 ? v : 100;
-  }();
-  const long resident = ((narrow3 && id == 7 && !radd && !split) ? 768 : 512) * resident_pct / 100;
+  // (launching only half of the co-resident workgroups, so that the kernels of the two block-half streams share every
+  // CU instead of taking turns, measured 9.51 / 9.58 vs 8.78 / 8.79 ms per step in round 3 -- removed)
+  const long resident = (narrow3 && id == 7 && !radd && !split) ? 768 : 512;
   // PDR_WS_XCD_ORDER: 1 (default) = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer,
   // 0 = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
   // (143 MB algorithmic), of the kNN-gathered narrow tiles 178 -> 143 MB, ball-gathered kernels unchanged; step time
@@ -1002,15 +1005,20 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   }();
   const int tile_order = (xcd_knob >= 2 || (xcd_knob == 1 && gath)) ? 1 : 0;
   long cap = (resident + ncol - 1) / ncol;
-  if (tile_order) cap = cap / 8 * 8;
+  // (whole groups of 8 workgroups for the XCD-local walk; fewer than 8 resident column-block workgroups -- ncol > 64
+  // -- keep the plain walk instead of rounding the grid down to nothing)
+  int tile_order_eff = tile_order;
+  if (tile_order && cap >= 8) cap = cap / 8 * 8;
+  else tile_order_eff = 0;
   if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa)
 #define PDR_WS_POOL(RT, CT, WR, WC, KC)                                                                       \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa)
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   const bool knn_res = in.rseg.gV && in.rseg.g_r1;
@@ -1035,7 +1043,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   if (pool && split) {
 #define PDR_WS_POOL_SPLIT(RT, CT, WR, WC, KC)                                                                  \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, true, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa)
     if (id == 4) PDR_WS_POOL_SPLIT(2, 2, 2, 2, 32);
     else if (id == 5) PDR_WS_POOL_SPLIT(1, 2, 2, 2, 32);
     else PDR_WS_POOL_SPLIT(1, 2, 4, 1, 32);

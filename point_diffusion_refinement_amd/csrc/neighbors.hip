@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (base <= 64) {
+    // base < K happens only when the distances are NaN (a non-finite query or point): no candidate passes
+    // `bits <= T`.  Those queries take the exact extraction below, which orders NaN keys by index and never leaves
+    // the output slots unwritten (the rank path then wrote nothing and stale LDS was stored).
+    if (base >= K && base <= 64) {
       const unsigned long long key = lane < base ? cand[wave][lane] : ~0ull;
       const unsigned klo = static_cast<unsigned>(key), khi = static_cast<unsigned>(key >> 32);
       int rank = 0;
@@ -240,7 +243,10 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
         unsigned long long best = ~0ull;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-          const unsigned long long key = pdr::u64_from(__float_as_uint(d[ch]), static_cast<unsigned>(ch * 64 + lane));
+          // (slots beyond the cloud never win: with NaN distances their +inf would sort FIRST as unsigned bits)
+          const unsigned long long key =
+              ch * 64 + lane < nc ? pdr::u64_from(__float_as_uint(d[ch]), static_cast<unsigned>(ch * 64 + lane))
+                                  : ~0ull;
           if ((r == 0 || key > last) && key < best) best = key;
         }
         best = ~pdr::wave_max_u64(~best);

@@ -55,7 +55,10 @@ class GradientAllReduce:
         assert all(p.dtype == params[0].dtype and p.device == params[0].device for p in params), \
             "a gradient bucket holds parameters of one dtype on one device"
         total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        # one extra element per parameter behind the gradients: 1 when THIS rank produced a gradient for it.  Summed by
+        # the same all-reduce it tells every rank whether ANY rank did -- a parameter no rank used keeps .grad = None,
+        # exactly like the reference's `param.grad is not None` filter (distributed.py:112) and a single-GPU run
+        flat = torch.zeros(total + len(params), dtype=params[0].dtype, device=params[0].device)
         items, off = [], 0
         for p in params:
             items.append((p, off, p.numel()))
@@ -78,10 +81,13 @@ class GradientAllReduce:
 
     def _launch(self, bi):
         flat, items = self.buckets[bi]
+        total = flat.numel() - len(items)
+        fired = [p in self._fired for p, _, _ in items]
         if self._pending[bi] > 0:                               # parameters without a gradient contribute zeros
-            for p, off, n in items:
-                if p not in self._fired:                       # (also covers a stale .grad of an earlier step)
+            for (p, off, n), f in zip(items, fired):
+                if not f:                                      # (also covers a stale .grad of an earlier step)
                     flat.narrow(0, off, n).zero_()
+        flat.narrow(0, total, len(items)).copy_(torch.tensor(fired, dtype=flat.dtype))
         self._handles.append((bi, dist.all_reduce(flat, group=self.group, async_op=True)))
         self._next = bi + 1
 
@@ -95,15 +101,22 @@ class GradientAllReduce:
         for bi, h in self._handles:
             h.wait()
             flat, items = self.buckets[bi]
-            flat.div_(self.world)
-            for p, off, n in items:
+            total = flat.numel() - len(items)
+            used = flat.narrow(0, total, len(items)).tolist()   # per parameter: how many ranks produced a gradient
+            flat.narrow(0, 0, total).div_(self.world)
+            for (p, off, n), cnt in zip(items, used):
                 avg = flat.narrow(0, off, n).view_as(p)
-                if p.grad is not None:
+                if p.grad is not None and p in self._fired:
                     p.grad.copy_(avg)
-                else:
-                    # no local gradient, but another rank may have produced one: every rank must apply the SAME
-                    # averaged gradient or the replicas diverge at the next optimizer step
-                    p.grad = avg.clone()
+                elif cnt > 0:
+                    # no local gradient, but another rank produced one: every rank must apply the SAME averaged
+                    # gradient or the replicas diverge at the next optimizer step
+                    if p.grad is not None:
+                        p.grad.copy_(avg)
+                    else:
+                        p.grad = avg.clone()
+                # else: no rank used this parameter in this backward -- .grad stays as it is (None after
+                # zero_grad(set_to_none=True)), as in the reference and in a single-process run
         self._handles = []
         self._pending = [len(items) for _, items in self.buckets]
         self._queued = False

@@ -35,56 +35,41 @@ from ..pointnet2_ops.attention import MyGroupNorm
 from .models.pointnet2_ssg_sem import calc_t_emb
 
 
-# First conv of every grouped block through per-point U / V tables + pdr_gather_add instead of a GEMM
-# over the materialised grouped tensor (see SplitFirstConv).  False = reference-shaped evaluation.
+# ---- evaluation variants --------------------------------------------------------------------------------------
+# Module constants, not environment knobs (round 4: the seventeen PDR_* reads are gone; the variants that lost their
+# A/B -- step embeddings ahead of the geometry fork, query-independent block halves on a third stream, row bounds on
+# the two-stream fork -- are deleted, DESIGN.md section 4.4 keeps their measurements).  What is left are the
+# reference-shaped / unfused forms of each fusion: tests monkeypatch them as cross-checks of the default, and
+# tests/test_fused_gpu.py::test_ddpm_forward_with_every_non_default_variant runs the full DDPM forward with each.
+# For same-box A/B runs the lab scripts set PDR_FUSED_OPTS="NAME=value,..." (parsed once, below).
+#
+# First conv of every grouped block through per-point U / V tables + pdr_gather_add instead of a GEMM over the
+# materialised grouped tensor (see SplitFirstConv).  False = reference-shaped evaluation.
 USE_SPLIT_FIRST = True
 # Attention score conv over [q.expand(K) | k]: evaluate the query half once per query (see FusedAttention)
 SPLIT_QUERY_CONV = True
 # Last attention score conv + mask + softmax + weighted sum in one kernel (scores never written): the pooled
 # epilogue of the wave-specialised layer kernel reduces the accumulators in place and reads the value rows in
-# accumulator layout.  Measured on MI355X (B = 32, same box, graph replay): 9.64 / 9.74 ms per step fused vs 10.30 /
-# 10.28 separate (round 1, on the uniform-wave kernel, it had lost 14.0 vs 13.5).  PDR_FUSE_SCORE_POOL=0: separate.
-FUSE_SCORE_POOL = __import__("os").environ.get("PDR_FUSE_SCORE_POOL", "1") == "1"
-# The first conv's (P x Cout) output is not written (ball-query blocks): its consumers (second MLP conv,
-# attention key) gather U[idx] + V in the producer waves of the wave-specialised layer kernel; only the
-# residual columns (a row-wise add in their consumer) are materialised, in the same pass that computes the
-# GroupNorm moments.  Measured on MI355X (B=32, same box): 12.28 ms/step vs 12.58 materialised.  The kNN form
-# carries two extra per-position terms and is always materialised.  PDR_VIRTUAL_FIRST=0 turns it off.
-# Feature-transfer blocks of level >= AHEAD_LEVEL can evaluate their query-independent part (grouping, shared MLP,
-# value conv) on a third stream as soon as the geometry is known.  Measured on MI355X (B=32, same box): OFF 11.65 /
-# 11.71 ms per step, levels >= 2 ahead 12.22 / 12.19, all levels 11.72 / 11.76 -- the persistent layer kernels of the
-# extra stream take workgroup slots (LDS) from the main stream's large kernels and the GPU timeline has no idle gaps
-# to fill (99.8 % covered).  So it is OFF (99); kept as the measured negative result.
-AHEAD_LEVEL = int(__import__("os").environ.get("PDR_AHEAD_LEVEL", "99"))
-# First call of a batch: run the condition branch through the fused blocks too (False: layer-by-layer torch path,
-# what rounds of this code did before; kept for A/B and as the cross-check of the tests).
-FUSE_CONDITION_BRANCH = __import__("os").environ.get("PDR_FUSE_CONDITION_BRANCH", "1") == "1"
-USE_VIRTUAL_FIRST = __import__("os").environ.get("PDR_VIRTUAL_FIRST", "1") == "1"
-# The same for the kNN (feature-propagation) blocks: consumers add the two per-position terms d2 r1 + w r2 in their
-# producer waves (GATH = 2 instantiations of the layer kernel).  PDR_VIRTUAL_KNN=0: materialised (A/B).
-USE_VIRTUAL_KNN = __import__("os").environ.get("PDR_VIRTUAL_KNN", "1") == "1"
-# The residual conv's columns of a virtual first conv (ball form) are not written either: the layer that adds the
-# residual gathers U_res[idx] + V_res in its producer waves (RADD + GATH instantiations of the layer kernel).
-# For residual windows of up to PDR_GATHER_RES channels (default: all; 0 = never).  Same box, graph replay: 9.35 ms per
-# step gathering only the 32-channel residuals, 9.24 up to 64, 9.20 all of them (ball form; with four query-row loads
-# per thread the wider kernels had spilled registers and lost).
-GATHER_RES = int(__import__("os").environ.get("PDR_GATHER_RES", "4096"))
-GATHER_RES_KNN = __import__("os").environ.get("PDR_GATHER_RES_KNN", "1") == "1"    # the kNN (FP) blocks' residuals too
-# Step embeddings + the first block's per-query tables issued BEFORE the geometry side stream is forked (see
-# FusedCloudConditionNet._forward_cached).  PDR_EARLY_EMBED=0 restores the round-1 order for A/B runs.
-# Measured (MI355X, B = 32, same box, graph replay): 11.42 ms/step with the embeddings beside the geometry stream vs
-# 11.57 ms issued ahead of the fork (B = 8: 5.82 vs 5.92) -- the later start of the FPS chain costs more than the
-# embedding launches save -- so the default stays OFF; the rocprofv3 timeline that suggested the opposite turned
-# out to be distorted by the tracer.  Re-measured at the end of round 3 (three native embedding launches instead of ~12
-# torch ones; the untraced markers put `embeddings_done` at 260 us, the first ball query at 104 us): 8.79 / 8.82 / 8.83
-# ahead of the fork vs 8.77 / 8.79 / 8.80 beside it -- still not a gain.
-EARLY_EMBED = __import__("os").environ.get("PDR_EARLY_EMBED", "0") == "1"
-# Geometry prepass: one event per level instead of one after the whole chain (see _forward_cached).
-# PDR_LEVEL_EVENTS=0 restores the single wait (A/B).
-LEVEL_EVENTS = __import__("os").environ.get("PDR_LEVEL_EVENTS", "1") == "1"
-# Step-embedding chain (sin / cos, fc_t1, swish, fc_t2, swish, every block's fc(t_emb)) as three pdr_embed_linear
-# launches instead of ~12 torch / hipBLASLt ones.  PDR_NATIVE_EMBED=0: the torch chain (A/B, cross-check).
-NATIVE_EMBED = __import__("os").environ.get("PDR_NATIVE_EMBED", "1") == "1"
+# accumulator layout.  MI355X, B = 32, same box: 9.64 / 9.74 ms per step fused vs 10.30 / 10.28 separate.
+FUSE_SCORE_POOL = True
+# First call of a batch: run the condition branch through the fused blocks too (False: layer-by-layer torch path;
+# the cross-check of test_fused_first_call_runs_the_condition_branch).
+FUSE_CONDITION_BRANCH = True
+# The first conv's (P x Cout) output is not written: its consumers (second MLP conv, attention key) gather
+# U[idx] + V in the producer waves of the wave-specialised layer kernel (12.28 vs 12.58 ms per step materialised) ...
+USE_VIRTUAL_FIRST = True
+# ... also for the kNN (feature-propagation) blocks: consumers add d2 r1 + w r2 in their producer waves (GATH = 2)
+USE_VIRTUAL_KNN = True
+# The residual conv's columns of a virtual first conv are not written either: the layer that adds the residual
+# gathers U_res[idx] + V_res (RADD + GATH instantiations), for residual windows of up to GATHER_RES channels
+# (9.35 ms gathering only the 32-channel residuals, 9.24 up to 64, 9.20 all of them); kNN blocks: GATHER_RES_KNN.
+GATHER_RES = 4096
+GATHER_RES_KNN = True
+# Geometry prepass: one event per level instead of one after the whole chain (-1.8 % step time at B = 32)
+LEVEL_EVENTS = True
+# Step-embedding chain as three pdr_embed_linear launches instead of ~12 torch / hipBLASLt ones (False: torch chain)
+NATIVE_EMBED = True
+LAB_SKIP_FOLD = False     # tools/lab probe, see Norm.fold
 
 
 def _stream():
@@ -261,26 +246,21 @@ class Conv:
 # Every grouped block evaluates its two independent halves -- shared MLP + value conv | query conv + score convs --
 # on two streams between the first GEMM and the pooling (parallel branches of the captured hipGraph).
 # `_PAR["stream"]` is set by the network around its forward.  Measured on MI355X (B = 32, same box, ms per step):
-# off 11.08 / 11.14, blocks of <= 65,536 positions 11.05 / 11.03, <= 1 M positions 10.94 / 10.94, all blocks
-# 10.89 / 10.88 (B = 8: 5.61 -> 5.30 with the deep levels alone): the small launches of one half fill the gaps and
-# tails of the other, also at level 0.  PDR_PAR_DEEP=0 turns it off, PDR_PAR_MAX_ROWS bounds it (A/B).
+# off 11.08 / 11.14, only the blocks of <= 65,536 positions 11.05 / 11.03, all blocks 10.89 / 10.88 (B = 8: 5.61 ->
+# 5.30 with the deep levels alone): the small launches of one half fill the gaps and tails of the other, also at
+# level 0 -- so every block forks (the row bounds of rounds 2-3 are gone).
 # Per-query first-conv tables ([V | V0]: coordinates x static weights; one thin launch per block) are evaluated on the
 # geometry stream as soon as a level's coordinates exist, ahead of that level's event, instead of at the head of
-# their block on the main stream.  Round 2 (tables after the WHOLE geometry chain, two launches per block): 10.85 /
-# 10.91 vs 10.87 / 10.87 ms, no gain.  Round 3 (per level, merged launch; same box, B = 32): 8.615 / 8.601 / 8.623 vs
-# 8.642 / 8.660 / 8.675 inside the blocks (B = 8: 4.17 vs 4.22) -- on.  PDR_SIDE_TABLES=0: inside the blocks.
-SIDE_TABLES = __import__("os").environ.get("PDR_SIDE_TABLES", "1") == "1"
+# their block on the main stream (8.615 / 8.601 / 8.623 vs 8.642 / 8.660 / 8.675 ms inside the blocks).
+SIDE_TABLES = True
 _PAR = {"stream": None}
-PAR_DEEP = __import__("os").environ.get("PDR_PAR_DEEP", "1") == "1"
-PAR_MAX_ROWS = int(__import__("os").environ.get("PDR_PAR_MAX_ROWS", str(1 << 40)))
-PAR_MIN_ROWS = int(__import__("os").environ.get("PDR_PAR_MIN_ROWS", "0"))     # (A/B: fork only blocks of >= this many rows)
 
 
 def _fork_join(rows, chain_a):
     """Run `chain_a()` on the auxiliary stream if this block qualifies; returns a thunk that joins and yields its
     result (or the result itself when everything stays on the current stream)."""
     aux = _PAR["stream"]
-    if aux is None or rows > PAR_MAX_ROWS or rows < PAR_MIN_ROWS:
+    if aux is None:
         return chain_a()
     main = torch.cuda.current_stream()
     fork = torch.cuda.Event()
@@ -301,10 +281,25 @@ def _fork_join(rows, chain_a):
 # (opt-in; FusedCloudConditionNet(precision=...) sets it around its forward).  See pack_f16x3 / run_layer.
 _PRECISION = ["f32"]
 # tile variants that have a split-f16 instantiation: 4 / 5 (128-column blocks), 8 (64-column blocks)
-SPLIT_VARIANTS = tuple(int(v) for v in __import__("os").environ.get("PDR_SPLIT_VARIANTS", "4,5,8").split(","))
+SPLIT_VARIANTS = (4, 5, 8)
 # layers with fewer input channels stay exact (HBM-bound: nothing to gain).  Same box, split step: 128 -> 7.33 ms, 64 ->
-# 7.16, 32 -> 7.16 (the 64-channel layers of the 64-column tiles are the ones that matter).  PDR_SPLIT_MIN_CIN: A/B
-SPLIT_MIN_CIN = int(__import__("os").environ.get("PDR_SPLIT_MIN_CIN", "64"))
+# 7.16, 32 -> 7.16 (the 64-channel layers of the 64-column tiles are the ones that matter)
+SPLIT_MIN_CIN = 64
+
+
+def _apply_lab_opts():
+    """PDR_FUSED_OPTS="NAME=value,NAME=value": lab override of the module constants above for same-box A/B runs
+    (tools/lab/ab_env.sh); values are parsed with the type of the constant they replace."""
+    spec = __import__("os").environ.get("PDR_FUSED_OPTS", "")
+    for item in filter(None, (t.strip() for t in spec.split(","))):
+        name, _, val = item.partition("=")
+        cur = globals().get(name)
+        if name.startswith("_") or not isinstance(cur, (bool, int)):
+            raise ValueError("PDR_FUSED_OPTS: unknown option %r" % name)
+        globals()[name] = (val.lower() in ("1", "true", "on")) if isinstance(cur, bool) else int(val)
+
+
+_apply_lab_opts()
 
 
 def pack_f16x3(Wt, Cout, seg_widths, TN=128):
@@ -463,6 +458,12 @@ class Norm:
         lib = _lib.load()
         dev = self.gamma.device
         assert 1 <= len(parts) <= 2 and sum(p[2] for p in parts) == C
+        if LAB_SKIP_FOLD:
+            # lab probe (never set in the product): the fold of a call site runs ONCE, later calls reuse its result --
+            # wrong values, right shapes: an upper bound on what taking the fold launches out of the step could buy
+            hit = self.__dict__.setdefault("_lab_fold", {}).get((B, C, n))
+            if hit is not None:
+                return hit
         scale = torch.empty((B, C), dtype=torch.float32, device=dev)
         shift = torch.empty((B, C), dtype=torch.float32, device=dev)
         (pa, ca, na, ta, ma) = parts[0]
@@ -474,6 +475,8 @@ class Norm:
         _lib.check(lib.pdr_gn_fold(_ptr(pa, 2 * ca), pa.shape[1], ta, na, float(ma), *second, B, self.Cn, self.G,
                                    float(n), float(self.eps), self.gamma.data_ptr(), self.beta.data_ptr(),
                                    scale.data_ptr(), shift.data_ptr(), _stream()), "gn_fold")
+        if LAB_SKIP_FOLD:
+            self._lab_fold[(B, C, n)] = (scale, shift)
         return scale, shift
 
 
@@ -990,7 +993,7 @@ class FusedGroupedBlock:
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
         B, m, _ = new_xyz.shape
         K = self.nsample
-        if not (USE_SPLIT_FIRST and _PAR["stream"] is not None and PAR_MIN_ROWS <= B * m * K <= PAR_MAX_ROWS):
+        if not (USE_SPLIT_FIRST and _PAR["stream"] is not None):
             return self.finish(self.prepare(src_xyz, src_feats_cl, new_xyz, bank, subset, neigh, V2=V2),
                                query_feats_cl)
         # deep level: first GEMM here, then [MLP + value conv] on the auxiliary stream beside [query / score convs]
@@ -1043,7 +1046,7 @@ class FusedKnnFP:
                 virtual=USE_VIRTUAL_FIRST and USE_VIRTUAL_KNN,
                 res=(self.mlp1.res_col0, self.mlp1.Clast) if self.mlp1.res_col0 is not None else None,
                 fold=self.mlp1.first_fold(n * K))
-            if _PAR["stream"] is not None and PAR_MIN_ROWS <= B * n * K <= PAR_MAX_ROWS:
+            if _PAR["stream"] is not None:
                 def chain_a():
                     hh, _, _, _ = self.mlp1.after_first(Y1, part1, tpb1, B * n * K, B, n * K, bank, folded=folded)
                     return self.att.values(hh, B, n, K)
@@ -1078,6 +1081,13 @@ class FusedCloudConditionNet:
         products -- eps within 1.2e-5 of the exact network -- for operands of ordinary magnitude, see
         include/pdr_hip.h pdr_fused_layer_f16x3)."""
         hp = net.hparams
+        if precision == "split_bf16":
+            # the name of rounds 1-2; the halves are f16 since round 3 (same call sites, different range contract:
+            # include/pdr_hip.h pdr_fused_layer_f16x3) -- accepted with a warning instead of breaking callers
+            import warnings
+            warnings.warn("precision='split_bf16' is a deprecated alias of 'split_f16' (f16 hi + lo halves; see the "
+                          "range contract in include/pdr_hip.h)", DeprecationWarning, stacklevel=2)
+            precision = "split_f16"
         if precision not in ("f32", "split_f16"):
             raise ValueError("precision must be 'f32' or 'split_f16'")
         self.precision = precision
@@ -1118,7 +1128,8 @@ class FusedCloudConditionNet:
         self._synced = False
         self._side = None
         self.return_strided_eps = False
-        self._label_key = None
+        self.two_streams = True       # the two halves of every block on two streams (False: profiling tools that want
+        self._label_key = None        # every kernel alone on the chip)
 
     def _side_stream(self):
         if self._side is None:
@@ -1207,7 +1218,7 @@ class FusedCloudConditionNet:
         saved = _PRECISION[0]
         _PRECISION[0] = self.precision
         saved_par = _PAR["stream"]
-        _PAR["stream"] = self._aux_stream() if PAR_DEEP else None
+        _PAR["stream"] = self._aux_stream() if self.two_streams else None
         try:
             if fresh:
                 _XYZ4.clear()
@@ -1290,21 +1301,6 @@ class FusedCloudConditionNet:
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
         l_uvw = net.l_uvw
 
-        # ---- everything that is small and needs no geometry goes FIRST, before the side stream is forked ----------
-        # Measured on MI355X (rocprofv3 timeline of a replayed step, profiles/r2_timeline notes in DESIGN.md): while
-        # the geometry stream runs a long kernel with dependent successors queued behind it (the FPS chain), the
-        # dependent small launches of the OTHER stream are dispatched at one per ~55 us.  The step embedding chain
-        # (sin / cos / cat, two Linear + swish, the per-block fc(t_emb) GEMM) and the first block's per-query tables
-        # used to sit exactly there: ~15 launches = ~0.75 ms before the first large kernel of the step started.
-        # Issued ahead of the fork they run back to back (~5 us each).  The condition / class embeddings do not
-        # change between the steps of a batch: their GEMMs run once per batch into static buffers.
-        early = EARLY_EMBED
-        if early:
-            self._embeddings(ts, label)
-            v2_first = self.enc_map[0].query_tables(enc_cl[0].shape[2], xyz, subset=False)
-        else:
-            v2_first = None
-
         # ---- geometry prepass on a side stream -------------------------------------------------
         # FPS chain, every ball query and every kNN search depend on coordinates only.  They are
         # latency / VALU-bound and (FPS) occupy 32 of 256 CUs, so they run beside the GEMMs of the
@@ -1327,8 +1323,6 @@ class FusedCloudConditionNet:
         with torch.cuda.stream(side):
             mark("side:begin")
             fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
-            if AHEAD_LEVEL == 0:
-                xyz4(xyz)
             if SIDE_TABLES and LEVEL_EVENTS and self.enc_map[0].split is not None:
                 tables[id(self.enc_map[0])] = self.enc_map[0].split.query_tables(xyz, has_v0=True)
             mark("side:first_ball_query_done")
@@ -1363,12 +1357,6 @@ class FusedCloudConditionNet:
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
                         fm_neigh[fm_key(i, blk)] = blk.neighbours(l_uvw[i], l_xyz[i])
-            if AHEAD_LEVEL <= nlev:
-                # the third stream reads the 16-byte padded coordinates too: produce them HERE (ordered before
-                # ev_all for every consumer) instead of lazily on whichever stream asks first.  Level 0 is used
-                # by the main stream right after ev_first, so it stays lazy (main) unless it is needed ahead.
-                for t in l_xyz[1:]:
-                    xyz4(t)
             mark("side:encoder_geometry_done")
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
@@ -1402,38 +1390,15 @@ class FusedCloudConditionNet:
             ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
             ev_knn.record(side)
 
-        # ---- embeddings (A/B: PDR_EARLY_EMBED=0 issues them here, beside the running geometry stream)
-        # (measured and dropped in round 3: the first ball query on the main stream with the FPS chain opening the
-        # geometry stream -- 8.81 / 8.79 / 8.82 vs 8.78 / 8.80 / 8.83 ms per step, no difference)
+        # ---- step embeddings, beside the running geometry stream.  (Issued ahead of the fork instead: 8.79 / 8.82 / 8.83
+        # vs 8.77 / 8.79 / 8.80 ms -- the FPS chain starts later; on the geometry stream behind the first ball query:
+        # 8.80 / 8.76 vs 8.73 / 8.73; DESIGN.md section 8.0.  Query-independent halves of the deep feature-transfer
+        # blocks ahead of time on a third stream: 12.22 / 11.72 vs 11.65 ms -- removed in round 4.)
         mark("main:before_embeddings", detail=True)
-        if not early:
-            self._embeddings(ts, label)
+        self._embeddings(ts, label)
         mark("main:embeddings_done")
 
-        # ---- query-independent parts of the deep feature-transfer blocks, ahead of time on a third stream
-        ahead = {}
-        if AHEAD_LEVEL <= nlev:
-            ev_bank = torch.cuda.Event()
-            ev_bank.record(main)
-            if getattr(self, "_ahead", None) is None:
-                self._ahead = torch.cuda.Stream(device=next(self.net.parameters()).device)
-            aux = self._ahead               # its own stream: the blocks fork their halves onto _aux_stream()
-            aux.wait_event(ev_all)
-            aux.wait_event(ev_bank)
-            todo = [(self.enc_map[l], l, enc_cl) for l in range(AHEAD_LEVEL, nlev)] + \
-                   [(self.dec_map[l], l, dec_cl) for l in range(nlev, AHEAD_LEVEL - 1, -1)]
-            with torch.cuda.stream(aux):
-                for blk, l, cl in todo:
-                    prep = blk.prepare(l_uvw[l], cl[l], l_xyz[l], bank, subset=False, neigh=fm_neigh[fm_key(l, blk)])
-                    ev = torch.cuda.Event()
-                    ev.record(aux)
-                    ahead[id(blk)] = (prep, ev)
-
         def transfer(blk, l, cl, query, V2=None):
-            hit = ahead.pop(id(blk), None)
-            if hit is not None:
-                main.wait_event(hit[1])
-                return blk.finish(hit[0], query)
             return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
 
         # ---- feature path ------------------------------------------------------------------------
@@ -1444,8 +1409,7 @@ class FusedCloudConditionNet:
         for i, sa in enumerate(self.sa):
             if LEVEL_EVENTS and i > 0:
                 main.wait_event(ev_fm[i])
-            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i],
-                              V2=v2_first if (i == 0 and v2_first is not None) else tables.get(id(self.enc_map[i])))
+            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])))
             mark("main:enc_map%d_done" % i)
             if LEVEL_EVENTS:
                 main.wait_event(ev_sa[i])
@@ -1471,7 +1435,6 @@ class FusedCloudConditionNet:
                                        V2=tables.get(id(self.fp[i])))
             mark("main:fp%d_done" % (i % (nlev + 1)))
         mapped = transfer(self.dec_map[0], 0, dec_cl, l_feat[0], V2=tables.get(id(self.dec_map[0])))
-        assert not ahead
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]
         head_in = Act([(mapped, 0, Cm, Cm, 1), (l_feat[0], 0, Cf, Cf, 1), (xyz4(xyz), 0, 3, 4, 1)], B * N, B, N)
         Y, _, _, (s, t) = run_layer(head_in, self.head1, fold=FoldReq(self.head_norm, self.head1.Cout, N))

@@ -105,7 +105,10 @@ def summarize(all_records):
 def generate_and_evaluate(generate, dataset, num_shapes, batch_size, rank=0, world_size=1, scale=1.0,
                           compute_emd=True, group=None, device=None):
     """Run this rank's shard.  `dataset(lo, hi)` -> (condition, label, gt) for partial indices [lo, hi)
-    (gt already expanded per partial view: gt_idx = index // 26, mvp_dataset.py:289).
+    (gt already expanded per partial view: gt_idx = index // 26, mvp_dataset.py:289) -- or, for a dataset that
+    augments during generation (`augment_data_during_generation`, completion_eval.py:140-143), the 5-tuple
+    (condition, label, gt, M_inv (b,3,3), translation (b,1,3)): generated clouds and gt are then mapped back with
+    `matmul(x - translation, M_inv)` before the metrics, as completion_eval.py:203-211 does.
     `device`: where an EMPTY shard's (0,5) record tensor lives (a rank past the end of the data still takes part
     in the collective, and under RCCL every rank must hand over a tensor on its own GPU); defaults to the
     current CUDA device when the process group's backend is nccl, else the CPU.
@@ -113,8 +116,14 @@ def generate_and_evaluate(generate, dataset, num_shapes, batch_size, rank=0, wor
     first, last, _, _ = rank_shard(num_shapes, rank, world_size)
     clouds, recs = [], []
     for lo, hi in batches(first, last, batch_size):
-        condition, label, gt = dataset(lo, hi)
-        g, r = evaluate_batch(generate, condition, label, gt, scale=scale, compute_emd=compute_emd)
+        item = dataset(lo, hi)
+        if len(item) not in (3, 5):
+            raise ValueError("dataset(lo, hi) must return (condition, label, gt) or (condition, label, gt, M_inv, "
+                             "translation); got %d items" % len(item))
+        condition, label, gt = item[:3]
+        M_inv, translation = item[3:] if len(item) == 5 else (None, None)
+        g, r = evaluate_batch(generate, condition, label, gt, scale=scale, compute_emd=compute_emd, M_inv=M_inv,
+                              translation=translation)
         clouds.append(g)
         recs.append(r)
     if recs:

@@ -57,3 +57,8 @@ def ddpm_inputs(B=1, N=2048, M=3072):
     ts = torch.full((B,), 500.0)
     label = torch.full((B,), 5, dtype=torch.long)
     return x.contiguous(), cond.contiguous(), ts, label
+
+
+def refine_coarse(B=1, N=2048):
+    """Coarse completed cloud handed to the refinement network: U[-1,1]^3 (the range of completed MVP shapes)."""
+    return (torch.rand(B, N, 3, generator=_gen(41)) * 2 - 1).contiguous()

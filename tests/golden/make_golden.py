@@ -165,6 +165,76 @@ def sampling_ddpm():
     save("sampling_ddpm.npz", out=out, xs=torch.stack(rec.xs))
 
 
+def sampling_ddpm_b6():
+    """`sampling` (util.py:184-255) at FULL size with MORE clouds and FEWER calls (B = 6, T = 3, seed 322): with three
+    network calls per cloud some clouds finish without a flipped discrete decision, so the final-coordinate check of
+    the HIP paths at north_star's 1e-4 is not vacuous."""
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    from util import calc_diffusion_hyperparams, sampling
+    from tests.parity import InputRecorder
+    x, cond, _, label = I.ddpm_inputs(B=6)
+    net = fill_deterministic(PointNet2CloudCondition(R.load_config()['pointnet_config']), 31).eval()
+    dh = calc_diffusion_hyperparams(3, 1e-4, 0.02)
+    rec = InputRecorder(net)
+    torch.manual_seed(322)
+    out = quiet(sampling, net, tuple(x.shape), dh, label=label, verbose=False, condition=cond)
+    rec.close()
+    save("sampling_ddpm_b6.npz", out=out, xs=torch.stack(rec.xs))
+
+
+def fastdpm_ddpm():
+    """configs[4], first stage, at FULL size: the reference's `fast_sampling_function_v2` (util_fastdpmv2.py:455-476 ->
+    VAR_sampling :307-381) with S = 50, 'var' / 'quadratic' / kappa = 0.5 on the shipped DDPM architecture, B = 1,
+    N = 2048, 3072-point condition, T = 1000 schedule, CPU noise stream of seed 323.  Stored: the generated cloud and
+    the x handed to EVERY one of the 50 network calls (teacher-forced per-step parity + free-running pre-flip parity).
+    The step search runs with the float64 promotion the reference was written against (see schedules())."""
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    from util import calc_diffusion_hyperparams
+    import util_fastdpmv2 as F
+    from tests.parity import InputRecorder
+    cfg = {"T": 1000, "beta_0": 1e-4, "beta_T": 0.02}
+    x, cond, _, label = I.ddpm_inputs(B=1)
+    net = fill_deterministic(PointNet2CloudCondition(R.load_config()['pointnet_config']), 31).eval()
+    dh = calc_diffusion_hyperparams(**cfg)
+    orig = F._log_cont_noise
+    F._log_cont_noise = lambda t, b0, bT, T: orig(t, np.float64(b0), np.float64(bT), T)
+    rec = InputRecorder(net)
+    try:
+        torch.manual_seed(323)
+        out = quiet(F.fast_sampling_function_v2, net, tuple(x.shape), dh, cfg, length=50, sampling_method='var',
+                    schedule='quadratic', kappa=0.5, label=label, verbose=False, condition=cond)
+    finally:
+        F._log_cont_noise = orig
+        rec.close()
+    assert len(rec.xs) == 50
+    save("fastdpm_ddpm.npz", out=out, xs=torch.stack(rec.xs))
+
+
+def refine_ddpm():
+    """configs[4], second stage, at FULL size: ONE refinement forward (completion_eval.py:159-168, `ts=None`) of the
+    reference network on the shipped refine-and-upsample-to-16384 architecture + `point_upsample` x8
+    (models/point_upsample_module.py:4-28, output_scale_factor 0.001), B = 1; coarse cloud ~ U[-1,1]^3 (seed 41)."""
+    import json
+    from json_reader import restore_string_to_list_in_a_dict
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    from models.point_upsample_module import point_upsample
+    with open(os.path.join(R.REF, "pointnet2/exp_configs/mvp_configs",
+                           "config_refine_and_upsample_16384_pts_standard_attention_10_trials.json")) as f:
+        cfg = json.load(f)
+    restore_string_to_list_in_a_dict(cfg)
+    pc, rc = cfg['pointnet_config'], cfg['refine_config']
+    _, cond, _, label = I.ddpm_inputs(B=1)
+    coarse = I.refine_coarse()
+    net = fill_deterministic(PointNet2CloudCondition(pc), 32).eval()
+    with torch.no_grad():
+        net.reset_cond_features()
+        disp = net(coarse, cond, ts=None, label=label)
+        fine, centre = point_upsample(coarse, disp, pc['point_upsample_factor'],
+                                      pc['include_displacement_center_to_final_output'], rc['output_scale_factor'])
+    assert tuple(fine.shape) == (1, 16384, 3)
+    save("refine_ddpm.npz", displacement=disp, refined=fine, centre=centre)
+
+
 def schedules():
     from util import calc_diffusion_hyperparams
     import util_fastdpmv2 as F
@@ -259,13 +329,11 @@ def state_dict_keys():
           (len(net.state_dict()), sum(p.numel() for p in net.parameters())))
 
 
+ALL = (layers, network, network_ddpm, sampling_ddpm, sampling_ddpm_b6, fastdpm_ddpm, refine_ddpm, schedules, metrics,
+       mirror, dataset, state_dict_keys)
+
 if __name__ == "__main__":
-    layers()
-    network()
-    network_ddpm()
-    sampling_ddpm()
-    schedules()
-    metrics()
-    mirror()
-    dataset()
-    state_dict_keys()
+    wanted = sys.argv[1:]                      # no arguments: regenerate everything
+    for fn in ALL:
+        if not wanted or fn.__name__ in wanted:
+            fn()

@@ -248,6 +248,67 @@ def test_xcd_local_tile_order_is_bit_identical(cuda, tmp_path):
     assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
 
 
+# (name, environment, must be bit-identical to the default run)
+_VARIANTS = [
+    # kernel-selection knobs of libpdr_hip.so (include/pdr_hip.h; read once per process)
+    ("ws_off", {"PDR_FUSED_WS": "0"}, False), ("narrow_kc16", {"PDR_NARROW_KC32": "0"}, False),
+    ("fps_wave0", {"PDR_FPS_WAVE": "0"}, True), ("fps_wave2", {"PDR_FPS_WAVE": "2"}, True),
+    ("knn_thread", {"PDR_KNN_WAVE": "0"}, True), ("narrow_2wg", {"PDR_WS_NARROW3": "0"}, True),
+    ("fold_1024_threads", {"PDR_GN_FOLD_SMALL": "0"}, False),
+    ("xcd_plain", {"PDR_WS_XCD_ORDER": "0"}, True), ("xcd_all", {"PDR_WS_XCD_ORDER": "2"}, True),
+    # evaluation variants of fused_network.py (module constants; PDR_FUSED_OPTS is the lab override)
+    ("no_score_pool", {"PDR_FUSED_OPTS": "FUSE_SCORE_POOL=0"}, False),
+    ("materialised_first", {"PDR_FUSED_OPTS": "USE_VIRTUAL_FIRST=0"}, False),
+    ("materialised_knn", {"PDR_FUSED_OPTS": "USE_VIRTUAL_KNN=0"}, False),
+    ("residual_written", {"PDR_FUSED_OPTS": "GATHER_RES=0"}, False),
+    ("residual_32", {"PDR_FUSED_OPTS": "GATHER_RES=32"}, False),
+    ("residual_knn_written", {"PDR_FUSED_OPTS": "GATHER_RES_KNN=0"}, False),
+    ("one_geometry_event", {"PDR_FUSED_OPTS": "LEVEL_EVENTS=0"}, True),
+    ("tables_in_blocks", {"PDR_FUSED_OPTS": "SIDE_TABLES=0"}, True),
+    ("torch_embedding_chain", {"PDR_FUSED_OPTS": "NATIVE_EMBED=0"}, False),
+    ("query_conv_unsplit", {"PDR_FUSED_OPTS": "SPLIT_QUERY_CONV=0"}, False),
+    ("grouped_first_conv", {"PDR_FUSED_OPTS": "USE_SPLIT_FIRST=0"}, False),
+    ("layerwise_condition_branch", {"PDR_FUSED_OPTS": "FUSE_CONDITION_BRANCH=0"}, False),
+]
+
+
+def test_ddpm_forward_with_every_non_default_variant(cuda, tmp_path):
+    """every surviving kernel-selection knob and evaluation variant, at its non-default values, on
+    the FULL DDPM architecture (one first + one cached forward, B = 2, fixed inputs => identical geometry): scheduling
+    variants give identical bytes, arithmetic variants stay within north_star's 1e-4 of the default evaluation."""
+    import os
+    import subprocess
+    import sys
+    from tests import parity
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jobs = [("default", {}, True)] + _VARIANTS
+    procs = []
+    results = {}
+
+    def reap(limit):
+        while len(procs) > limit:
+            name, p, path = procs.pop(0)
+            _, err = p.communicate()
+            assert p.returncode == 0, (name, err.decode()[-2000:])
+            results[name] = torch.load(path)
+    for name, env, _ in jobs:
+        path = str(tmp_path / (name + ".pt"))
+        e = dict(os.environ, **env)
+        procs.append((name, subprocess.Popen([sys.executable, "-m", "tools.variant_check", path], cwd=root, env=e,
+                                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE), path))
+        reap(7)                                            # at most 8 children at a time
+    reap(0)
+    base = results["default"]
+    assert all(bool(torch.isfinite(v).all()) for v in base.values())
+    for name, _, identical in _VARIANTS:
+        for call in ("first", "cached"):
+            got, want = results[name][call], base[call]
+            if identical:
+                assert torch.equal(got, want), (name, call, float((got - want).abs().max()))
+            else:
+                parity.check("variant:%s:%s" % (name, call), "hip", got, want, 1e-4)
+
+
 def test_graphed_sampler_options_t_slices_and_precomputed_xt(cuda):
     """GraphedReverseSampler.sample(return_multiple_t_slices=, use_a_precomputed_XT=) (util.py:217-222, 246-248): the
     slice steps run eagerly through PyTorch ops, every other step as a graph replay; against the layer-by-layer
@@ -280,7 +341,7 @@ def test_graphed_sampler_options_t_slices_and_precomputed_xt(cuda):
 def test_second_batch_with_other_labels_through_the_captured_graph(cuda, fuse_branch, monkeypatch):
     """The class-embedding rows of the blocks live in a static buffer that a captured step only READS: a second batch
     with DIFFERENT labels must refresh them before its replays -- also when the first step of a batch takes the
-    layer-by-layer path (PDR_FUSE_CONDITION_BRANCH=0) and never reaches the embedding bank."""
+    layer-by-layer path (FUSE_CONDITION_BRANCH = False) and never reaches the embedding bank."""
     monkeypatch.setattr(FN, "FUSE_CONDITION_BRANCH", fuse_branch)
     net, fused = _pair(small_fused_config(), 23, cuda)
     dh = util.calc_diffusion_hyperparams(5, 1e-4, 0.02)
@@ -807,6 +868,46 @@ def test_split_f16_representation_floor(cuda, magnitude, bar, monkeypatch):
     assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), "split path not taken"
     err = float(((Y[:, :Cout].double() - ref).abs() / bound).max())
     assert err < bar, err
+
+
+def test_split_f16_large_activations_saturate_instead_of_nan(cuda, monkeypatch):
+    """ADVICE r3 / include/pdr_hip.h range contract: activations beyond the f16 range.  65504 < |x| <= 131008 is
+    carried by hi = +-65504 plus lo (MODE.FP16_OVFL clamps the conversions) at 2^-12 relative or better; beyond that the
+    operand saturates -- the output is FINITE and equals the product of the clamped operand; never NaN / inf (which is
+    what hi = inf, lo = x - inf = -inf produced before)."""
+    P, Cin, Cout, rpb = 1 << 12, 128, 128, 1024
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(P, Cin, generator=g)
+    x[::7, ::5] *= 4.0e4                                   # many values in (65504, 131008]
+    x[3::64, 1::9] = 9.0e4 * torch.sign(x[3::64, 1::9])
+    inside = x.clone()
+    assert float(inside.abs().max()) <= 131008 and int((inside.abs() > 65504).sum()) > 100
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    conv = _conv(W, torch.zeros(Cout, device=cuda))
+    monkeypatch.setattr(FN, "_PRECISION", ["split_f16"])
+    lib = _lib.load()
+
+    def run(xin):
+        xin = xin.to(cuda)
+        act = FN.Act([(xin, 0, Cin, Cin, 1)], P, P // rpb, rpb)
+        Y = torch.empty((P, FN._ldy(Cout)), device=cuda)
+        tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+        part = torch.empty(((P // rpb) * ((rpb + tm - 1) // tm), Cout, 2), device=cuda)
+        assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), \
+            "split path not taken"
+        return Y[:, :Cout].double().cpu(), xin.double().cpu()
+    Y, xd = run(inside)
+    assert bool(torch.isfinite(Y).all())
+    ref = xd @ W.t().double().cpu()
+    bound = xd.abs() @ W.t().abs().double().cpu()
+    assert float(((Y - ref).abs() / bound).max()) < 2.0 ** -11       # worst operand: 2^-12 relative
+    beyond = inside.clone()
+    beyond[5::128, 2::11] = 1.0e6                                     # far outside: saturates at 131008
+    Y2, xd2 = run(beyond)
+    assert bool(torch.isfinite(Y2).all()), "saturation must not produce inf / NaN"
+    ref2 = xd2.clamp(-131008.0, 131008.0) @ W.t().double().cpu()
+    assert float(((Y2 - ref2).abs() / (xd2.clamp(-131008.0, 131008.0).abs() @ W.t().abs().double().cpu())).max()) \
+        < 2.0 ** -11
 
 
 def test_split_f16_network_and_sampler(cuda):

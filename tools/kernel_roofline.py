@@ -152,15 +152,17 @@ def measured_traffic(symbol):
     raise LookupError("%s has no entry for %s -- re-run tools/profile_round.sh" % (os.path.basename(path), symbol))
 
 
-def step_kernel_table(sampler, reps=3, overlapped=False):
+def step_kernel_table(sampler, reps=3):
     """HIP-event timing of every C-ABI launch of `reps` eager steps -> {symbol: [n, ms, flops, bytes]}.
-    overlapped=False: the blocks' two halves run on ONE stream for the measurement, so an event bracket times a
-    kernel that has the chip to itself (what a kernel roofline is about); True: as the step really runs (two
-    streams), where a launch shares the CUs with the other half's kernels and its bracket is longer."""
-    from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
+    The blocks' two halves run on ONE stream for the measurement, so an event bracket times a kernel that has the
+    chip to itself (what a kernel roofline is about).  How long the same launch takes INSIDE the two-stream graph
+    replay is not something eager event brackets can show (round 3 reported such a figure; the rocprofv3 kernel
+    trace of the replayed step disagreed): that number is profiles/*_bench_kernel_stats.csv's."""
     lib = _lib.load()
-    saved_par = FN.PAR_DEEP
-    FN.PAR_DEEP = bool(overlapped) and saved_par
+    net = sampler.net
+    saved_par = getattr(net, "two_streams", None)
+    if saved_par is not None:
+        net.two_streams = False
     records = []
     installed = []
     for name in _TIMED:
@@ -186,7 +188,8 @@ def step_kernel_table(sampler, reps=3, overlapped=False):
                 sampler._step()           # eager: the graph is not involved
         torch.cuda.synchronize()
     finally:
-        FN.PAR_DEEP = saved_par
+        if saved_par is not None:
+            net.two_streams = saved_par
         for name, fn in installed:
             setattr(lib, name, fn)        # back to the CDLL's own (typed) function object
     table = collections.OrderedDict()
@@ -221,16 +224,6 @@ def dominant_kernel_roofline(sampler, reps=3):
     ranked = sorted(table.items(), key=lambda kv: -kv[1][1])
     sym, (n, ms, fl, by, kind) = ranked[0]
     out = _roof(fl, by, ms, sym, kind)
-    try:
-        ovl = step_kernel_table(sampler, 2, overlapped=True).get(sym)
-        if ovl:
-            r = _roof(ovl[2], ovl[3], ovl[1], sym, kind)
-            out["in_step_two_streams"] = {"avg_launch_us": round(ovl[1] / ovl[0] * 1e3, 2), "achieved": r["achieved"],
-                                          "frac": r["frac"],
-                                          "note": "same launches while the other half of each block runs beside them "
-                                                  "(how the step executes; agrees with profiles/*_bench_kernel_stats.csv)"}
-    except Exception as e:   # instrumentation only
-        out["in_step_two_streams"] = {"error": repr(e)}
     try:
         out["traffic"], out["traffic_source"] = measured_traffic(sym)
     except (LookupError, OSError, KeyError, ValueError) as e:

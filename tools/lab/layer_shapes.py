@@ -46,8 +46,8 @@ def main():
                      e0, e1))
         return rc
 
-    saved = FN.PAR_DEEP
-    FN.PAR_DEEP = False
+    saved = sampler.net.two_streams
+    sampler.net.two_streams = False
     lib.pdr_fused_layer = timed
     try:
         with torch.no_grad():
@@ -59,7 +59,7 @@ def main():
         torch.cuda.synchronize()
     finally:
         lib.pdr_fused_layer = fn
-        FN.PAR_DEEP = saved
+        sampler.net.two_streams = saved
     agg = collections.OrderedDict()
     for P, rpb, Cin, Cout, segs, flags, rc0, sym, e0, e1 in rows:
         k = (P, rpb, Cin, Cout, segs, flags, rc0, sym)

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o s -
 tail -1 $OUT/${TAG}_stats.log | cut -c1-200
 # the same with the two halves of every block on ONE stream: per-kernel durations of kernels that have the chip to
 # themselves (the figure a kernel roofline is about; bench.py's `roofline` is measured the same way)
-PDR_PAR_DEEP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o s -- $BENCH --steps 20 > $OUT/${TAG}_stats_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o s -- $BENCH --single-stream --steps 20 > $OUT/${TAG}_stats_serial.log 2>&1
 cp $(find $OUT/${TAG}_stats_serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats_serial.csv
 rm -rf $OUT/${TAG}_stats_serial
 if [ -n "$PDR_PROFILE_QUICK" ]; then   # kernel stats + step timeline only (no counter passes)

@@ -1,0 +1,33 @@
+"""Child process of tests/test_fused_gpu.py::test_ddpm_forward_with_every_non_default_variant: ONE first (uncached)
+and ONE cached forward of the fused network on the shipped DDPM architecture (B = 2, seeded inputs and weights) under
+whatever kernel-selection knobs (PDR_* of include/pdr_hip.h, read once per process) and evaluation variants
+(PDR_FUSED_OPTS, point_diffusion_refinement_amd/pointnet2/fused_network.py) the environment carries; writes both eps.
+    PDR_FUSED_WS=0 python -m tools.variant_check /tmp/eps.pt"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from point_diffusion_refinement_amd.pointnet2.configs import ddpm_pointnet_config, synthetic_batch
+    from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
+    from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(dev)
+    fused = FusedCloudConditionNet(net, precision=os.environ.get("VARIANT_PRECISION", "f32"))
+    x, cond, label = synthetic_batch(2, seed=3, device=dev)
+    ts = torch.tensor([500.0, 20.0], device=dev)
+    with torch.no_grad():
+        first = fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        cached = fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+    torch.cuda.synchronize()
+    torch.save({"first": first.cpu(), "cached": cached.cpu()}, sys.argv[1])
+
+
+if __name__ == "__main__":
+    main()
