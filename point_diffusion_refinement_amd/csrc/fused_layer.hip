@@ -629,6 +629,10 @@ __global__ __launch_bounds__(1024) void gn_fold_wide_kernel(FoldPart p0, FoldPar
 // persistent 512-thread layer workgroups; rocprofv3: 23.5 us per fold inside the two-stream step vs 7 us alone).
 // Lanes 0-31 / 32-63 of a wave read the same 32 channels (256 contiguous bytes of a tile's partial row) of two
 // different tile slices; 8 slices per workgroup, four loads in flight per thread; double sums, fixed order.
+// U = partial rows in flight per thread and trip: 4 for up to 128 tiles per batch element (one or two trips), 16 above --
+// the level-0 layers have 256 / 512 tiles per batch element, i.e. 32 / 64 rows per thread, and every trip is a dependent
+// round trip to rows another kernel has just written (~1 us): 16 trips -> 4 (round 4; tools/lab/gn_fold_bench.py).
+template <int U>
 __global__ __launch_bounds__(256) void gn_fold_kernel(FoldPart p0, FoldPart p1, int C, int Cn, int G, int CW,
                                                       double n, float eps,
                                                       const float* __restrict__ gamma,
@@ -657,17 +661,17 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(FoldPart p0, FoldPart p1, 
     mult = p.mult;
     const long stride = static_cast<long>(p.ldp) * 2;
     const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + col) * 2;
-    for (int t = sl; t < p.tiles_per_batch; t += 32) {
-      // four loads in flight: unconditional, from a clamped tile (t itself is valid), zeroed afterwards -- a load
-      // under `tt < tiles` compiles to a branch with its own vmcnt(0), i.e. four dependent round trips per trip
-      float2 v[4];
+    for (int t = sl; t < p.tiles_per_batch; t += 8 * U) {
+      // U loads in flight: unconditional, from a clamped tile (t itself is valid), zeroed afterwards -- a load
+      // under `tt < tiles` compiles to a branch with its own vmcnt(0), i.e. U dependent round trips per trip
+      float2 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int tt = t + 8 * u;
         v[u] = *reinterpret_cast<const float2*>(q + (tt < p.tiles_per_batch ? tt : t) * stride);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const bool ok = t + 8 * u < p.tiles_per_batch;
         s1 += ok ? v[u].x : 0.0f;
         s2 += ok ? v[u].y : 0.0f;
@@ -843,6 +847,8 @@ inline TileCfg pick_tile(int rows_per_batch, int Cout) {
   if (rows_per_batch >= 256 && Cout <= 64) return {256, 64, 1};
   if (rows_per_batch >= 128 && Cout <= 96) return {128, 96, 2};
   if (rows_per_batch >= 128 && Cout > 128 && Cout <= 160) return {128, 160, 3};
+  // (64-row tiles for the deep levels, whose 128 x 128 tiling has fewer jobs than the 512 resident workgroups -- B = 32:
+  // 16 k rows x 128 columns = 128 jobs -- measured 8.72-8.77 vs 8.75-8.77 ms per step in round 4: no gain, not taken)
   if (rows_per_batch >= 128) return {128, 128, 4};
   if (rows_per_batch >= 64) return {64, 128, 5};
   return {32, 128, 6};
@@ -1202,8 +1208,13 @@ extern "C" int pdr_gn_fold(const float* part0, int ldp0, int tpb0, int C0, doubl
     // windows of whole groups covering <= 32 channels; one more workgroup row for pass-through channels
     const int CW = (32 / cpg) * cpg;
     const int nw = (Cn + CW - 1) / CW + (C > Cn ? 1 : 0);
-    hipLaunchKernelGGL(gn_fold_kernel, dim3(nw, B), dim3(256), 0, pdr::as_stream(stream), p0, p1, C, Cn, G,
-                       CW, n, eps, gamma, beta, scale, shift);
+    // (same sums in the same order for either U: slices of 8 tiles, rows ascending within a slice)
+    if (tpb0 > 128 || (part1 && tpb1 > 128))
+      hipLaunchKernelGGL(gn_fold_kernel<16>, dim3(nw, B), dim3(256), 0, pdr::as_stream(stream), p0, p1, C, Cn, G,
+                         CW, n, eps, gamma, beta, scale, shift);
+    else
+      hipLaunchKernelGGL(gn_fold_kernel<4>, dim3(nw, B), dim3(256), 0, pdr::as_stream(stream), p0, p1, C, Cn, G,
+                         CW, n, eps, gamma, beta, scale, shift);
     return pdr::check_launch();
   }
   if (static_cast<size_t>(C) * 16 > 48 * 1024) return PDR_EUNSUPPORTED;
