@@ -319,6 +319,9 @@ int pdr_gn_fold(const float *part0, int ldp0, int tpb0, int C0, double mult0, co
 /* out (P,C; ld ldo) = prologue(X): materialise an activation descriptor */
 int pdr_apply_act(const pdr_layer_in_t *in, long P, int C, float *out, int ldo,
                   pdr_stream_t stream);
+/* out (B,C) = max over the rows of every batch element of prologue(X) (plain sources, no residual): the global
+ * max-pooling of Pnet2Stage (pnet.py:27-40: F.max_pool2d over all points) on a lazily-activated layer output */
+int pdr_act_colmax(const pdr_layer_in_t *in, long P, int C, float *out, pdr_stream_t stream);
 /* GroupNorm(G groups over the first Cn of C channels; the rest pass through), n elements
  * per channel per batch element -> scale, shift (B,C) */
 int pdr_gn_finalize(const double *chan_stats, int B, int C, int Cn, int G, double n, float eps,

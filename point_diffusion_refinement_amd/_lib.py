@@ -50,6 +50,7 @@ SIGNATURES = {
     "pdr_fused_layer_pool_f16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "pdr_gn_reduce": (_I, [_P, _I, _I, _I, _I, _c.c_double, _P, _I, _I, _P]),
     "pdr_apply_act": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
+    "pdr_act_colmax": (_I, [_P, _c.c_long, _I, _P, _P]),
     "pdr_gn_fold": (_I, [_P, _I, _I, _I, _c.c_double, _P, _I, _I, _I, _c.c_double, _I, _I, _I, _c.c_double, _F,
                          _P, _P, _P, _P, _P]),
     "pdr_gn_finalize": (_I, [_P, _I, _I, _I, _I, _c.c_double, _F, _P, _P, _P, _P, _P]),

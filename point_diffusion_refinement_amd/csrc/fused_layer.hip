@@ -730,6 +730,46 @@ __global__ __launch_bounds__(256) void apply_act_kernel(pdr_layer_in_t in, long 
   out[row * ldo + c] = v;
 }
 
+// out (B, C) = max over the rows of every batch element of prologue(X): the global max-pooling of Pnet2Stage
+// (pnet.py:27-40 of the reference: F.max_pool2d over all points) applied to a layer's lazily-activated output, without
+// materialising the activation.  256 threads = 64 channels x 4 row slices; a wave reads 256-byte row pieces.
+__global__ __launch_bounds__(256) void act_colmax_kernel(pdr_layer_in_t in, int C, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y;
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int rpb = in.rows_per_batch;
+  float m = -__builtin_inff();
+  if (c < C) {
+    const ColSrc src = resolve_col(in, c);
+    const int ss_ld = in.ss_ld > 0 ? in.ss_ld : C;
+    const float s = in.scale ? in.scale[static_cast<long>(b) * ss_ld + c] : 1.0f;
+    const float h = in.shift ? in.shift[static_cast<long>(b) * ss_ld + c] : 0.0f;
+    const float a = in.add ? in.add[static_cast<long>(b) * in.add_ld + c] : 0.0f;
+    const long row0 = static_cast<long>(b) * rpb;
+    for (int r = sl; r < rpb; r += 16) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 4 * u;
+        v[u] = load_col(src, row0 + (rr < rpb ? rr : r));       // (clamped: unconditional loads, all in flight)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x = v[u];
+        if (in.pre_relu) x = fmaxf(x, 0.0f);
+        x = __builtin_fmaf(x, s, h);
+        if (in.post_relu) x = fmaxf(x, 0.0f);
+        m = fmaxf(m, x + a);
+      }
+    }
+  }
+  red[sl][cl] = m;
+  __syncthreads();
+  if (sl == 0 && c < C)
+    out[static_cast<long>(b) * C + c] = fmaxf(fmaxf(red[0][cl], red[1][cl]), fmaxf(red[2][cl], red[3][cl]));
+}
+
 // GroupNorm(G groups over the first Cn of C channels, eps) folded to y = x*scale + shift;
 // channels >= Cn pass through (MyGroupNorm).  n = elements per channel per batch.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ chan_stats, int C,
@@ -1238,6 +1278,25 @@ extern "C" int pdr_apply_act(const pdr_layer_in_t* in, long P, int C, float* out
   if (ctot != C) return PDR_EINVAL;
   hipLaunchKernelGGL(apply_act_kernel, dim3(static_cast<unsigned>((P * C + 255) / 256)), dim3(256), 0,
                      pdr::as_stream(stream), *in, P, C, out, ldo);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_act_colmax(const pdr_layer_in_t* in, long P, int C, float* out, pdr_stream_t stream) {
+  if (!in || !out || P < 0 || C <= 0 || in->n_seg < 1 || in->n_seg > 4 || in->rows_per_batch <= 0 ||
+      P % in->rows_per_batch != 0)
+    return PDR_EINVAL;
+  if (in->rseg.ptr || in->oadd) return PDR_EUNSUPPORTED;   // plain prologue only
+  if (P == 0) return PDR_OK;
+  int ctot = 0;
+  for (int s = 0; s < in->n_seg; ++s) {
+    if (!in->seg[s].ptr || in->seg[s].row_div < 1 || (in->seg[s].row_div & (in->seg[s].row_div - 1)))
+      return PDR_EUNSUPPORTED;
+    if (in->seg[s].gV) return PDR_EUNSUPPORTED;
+    ctot += in->seg[s].C;
+  }
+  if (ctot != C) return PDR_EINVAL;
+  const dim3 grid(static_cast<unsigned>((C + 63) / 64), static_cast<unsigned>(P / in->rows_per_batch));
+  hipLaunchKernelGGL(act_colmax_kernel, grid, dim3(256), 0, pdr::as_stream(stream), *in, C, out);
   return pdr::check_launch();
 }
 

@@ -69,7 +69,14 @@ GATHER_RES_KNN = True
 LEVEL_EVENTS = True
 # Step-embedding chain as three pdr_embed_linear launches instead of ~12 torch / hipBLASLt ones (False: torch chain)
 NATIVE_EMBED = True
-LAB_SKIP_FOLD = False     # tools/lab probe, see Norm.fold
+# The global PointNet of a new batch (models/pnet.py) through the fused layer kernels (False: the torch module ->
+# MIOpen convolutions, what rounds 1-3 did)
+FUSE_GLOBAL_PNET = True
+# Lab probe (never changed in the product): LAB_SKIP_FOLD reuses every GroupNorm fold's first result -- wrong values,
+# right launches minus the folds: the 0.5 ms bound of DESIGN.md section 4.5.  (Stream priorities, measured in round 4:
+# the geometry stream or the blocks' second-half stream at HIP priority -1 beside normal-priority streams 11.5-12.0 ms
+# per step vs 8.75 -- kernels of different priorities no longer overlap; both at -1: 8.81-8.85; not used.)
+LAB_SKIP_FOLD = False
 
 
 def _stream():
@@ -525,12 +532,26 @@ class EmbeddingBank:
     def evaluate_kind(self, kind, src, static=False):
         """One embedding kind.  static=True: the result is written IN PLACE into the buffer of the previous call
         (same shape), so that a captured hipGraph -- which does not contain this GEMM -- keeps reading a valid
-        address whose contents follow the batch."""
+        address whose contents follow the batch.  On the GPU the GEMM is pdr_embed_linear (round 4: the condition /
+        class embedding rows of a new batch ran through F.linear -> hipBLASLt, 2 x 820 us for B = 32 rows)."""
         if kind not in self.W:
             return
-        val = F.linear(src, self.W[kind], self.b[kind])
+        W, b = self.W[kind], self.b[kind]
         old = self.out.get(kind)
-        if static and old is not None and old.shape == val.shape and old.device == val.device:
+        reuse = static and old is not None and old.shape == (src.shape[0], W.shape[0]) and old.device == src.device
+        if NATIVE_EMBED and src.is_cuda and src.dtype == torch.float32 and src.dim() == 2 and W.shape[1] % 8 == 0:
+            x = src if (src.is_contiguous() and src.data_ptr() % 16 == 0 and src.shape[1] % 4 == 0) else \
+                src.contiguous().clone()
+            out = old if reuse else torch.empty((x.shape[0], W.shape[0]), dtype=torch.float32, device=x.device)
+            rc = _lib.load().pdr_embed_linear(x.data_ptr(), x.shape[1], None, 0, None, 0, W.data_ptr(), b.data_ptr(),
+                                              x.shape[0], x.shape[1], W.shape[0], 0, out.data_ptr(), out.shape[1],
+                                              _stream())
+            if rc != _lib.PDR_EUNSUPPORTED:
+                _lib.check(rc, "embed_linear")
+                self.out[kind] = out
+                return
+        val = F.linear(src, W, b)
+        if reuse:
             old.copy_(val)
         else:
             self.out[kind] = val
@@ -1072,6 +1093,74 @@ class FusedKnnFP:
         return materialize(h2).view(B, n, -1)
 
 
+def act_colmax(act):
+    """(B, C) = max over every batch element's rows of the lazily-activated `act` (pdr_act_colmax)."""
+    out = torch.empty((act.B, act.C), dtype=torch.float32, device=act.segs[0][0].device)
+    li = act.struct()
+    _lib.check(_lib.load().pdr_act_colmax(ctypes.byref(li), act.P, act.C, out.data_ptr(), _stream()), "act_colmax")
+    return out
+
+
+class FusedPnet2Stage:
+    """Pnet2Stage (models/pnet.py; reference pnet.py:7-40) -- the global PointNet that summarises the condition cloud
+    once per batch -- on the fused layer kernels: per-point MLP (conv -> GroupNorm -> ReLU, twice), max over the
+    points, [feature | global].expand -> MLP -> max.  Round 3 ran it through torch Conv2d -> MIOpen (naive_conv /
+    miopen rows in the first-step profile).  The concatenation with the broadcast global vector is never built: the
+    second stage reads the first stage's output twice -- once with its GroupNorm folded in, once with scale 0 -- and
+    the global vector enters as the per-batch `add` row of the second read."""
+
+    def __init__(self, pnet):
+        def stages(mlp):
+            if mlp.first_conv_bool or mlp.include_t or mlp.include_condition or mlp.include_second_condition or \
+                    mlp.res_connect_bool or mlp.rest_mlp is not None:
+                raise NotImplementedError("fused Pnet2Stage: plain two-layer MLPs")
+            out = []
+            for seq in (mlp.first_mlp, mlp.second_mlp):
+                mods = list(seq)
+                if not isinstance(mods[0], nn.Conv2d):
+                    raise NotImplementedError("fused Pnet2Stage: conv -> GroupNorm -> ReLU stages")
+                if len(mods) == 1:
+                    out.append((Conv([mods[0]]), None))                     # remove_last_activation: conv only
+                elif len(mods) == 3 and isinstance(mods[1], MyGroupNorm) and isinstance(mods[2], nn.ReLU):
+                    out.append((Conv([mods[0]]), Norm(mods[1])))
+                else:
+                    raise NotImplementedError("fused Pnet2Stage: conv -> GroupNorm -> ReLU stages")
+            return out
+        self.s1, self.s2 = stages(pnet.mlp1), stages(pnet.mlp2)
+        if self.s1[0][1] is None or self.s2[0][1] is None:
+            raise NotImplementedError("fused Pnet2Stage: the first layer of a stage is normalised")
+
+    @staticmethod
+    def _mlp(x, stages, B, n):
+        """x: Act -> Act of the stage's output (its last GroupNorm + ReLU folded in lazily, if it has one)."""
+        (c1, n1), (c2, n2) = stages
+        Y1, _, _, (s, t) = run_layer(x, c1, fold=FoldReq(n1, c1.Cout, n))
+        a1 = Act([(Y1, 0, c1.Cout, Y1.shape[1], 1)], B * n, B, n, scale=s, shift=t, post_relu=True)
+        if n2 is None:
+            Y2 = run_layer(a1, c2)[0]
+            return Act([(Y2, 0, c2.Cout, Y2.shape[1], 1)], B * n, B, n)
+        Y2, _, _, (s, t) = run_layer(a1, c2, fold=FoldReq(n2, c2.Cout, n))
+        return Act([(Y2, 0, c2.Cout, Y2.shape[1], 1)], B * n, B, n, scale=s, shift=t, post_relu=True)
+
+    def __call__(self, g_in):
+        """g_in (B, n, Cin) channel-last -> (B, C_out) global feature."""
+        B, n, _ = g_in.shape
+        x = Act(feature_segments(g_in), B * n, B, n)
+        f = self._mlp(x, self.s1, B, n)
+        g = act_colmax(f)                                                   # (B, C1)
+        C1 = f.C
+        Y, _, _, ld, _ = f.segs[0]
+        dev = g.device
+        one = torch.ones((B, C1), device=dev) if f.scale is None else f.scale
+        zero = torch.zeros((B, C1), device=dev)
+        # [f | g.expand(n)]: the second half = the same rows at scale 0 (finite values x 0 = 0) + the `add` row g
+        both = Act([(Y, 0, C1, ld, 1), (Y, 0, C1, ld, 1)], B * n, B, n,
+                   scale=torch.cat([one, zero], 1).contiguous(),
+                   shift=torch.cat([zero if f.shift is None else f.shift, zero], 1).contiguous(),
+                   add=torch.cat([zero, g], 1).contiguous(), add_ld=2 * C1, post_relu=f.post_relu)
+        return act_colmax(self._mlp(both, self.s2, B, n))
+
+
 class FusedCloudConditionNet:
     """Cached-condition forward of PointNet2CloudCondition through the fused kernels."""
 
@@ -1124,6 +1213,10 @@ class FusedCloudConditionNet:
             raise NotImplementedError("fused path: Conv1d -> GroupNorm -> ReLU -> Conv1d head")
         self.head1, self.head_norm, self.head2 = Conv([head[0]]), Norm(head[1]), Conv([head[3]])
         b.pack()
+        try:
+            self.global_pnet = FusedPnet2Stage(net.global_pnet)
+        except NotImplementedError:
+            self.global_pnet = None              # (outside the fused family: the torch module computes it)
         self.enc_cl = self.dec_cl = None
         self._synced = False
         self._side = None
@@ -1183,7 +1276,10 @@ class FusedCloudConditionNet:
             if condition.shape[2] > 3 else (uvw / net.scale_factor)
         raw = net.partial_in_fea_dim - 3 if net.attach_position_to_input_feature else net.partial_in_fea_dim
         g_in = torch.cat([uvw, condition[:, :, 3:3 + raw]], dim=2) if raw > 0 else uvw
-        net.global_feature = net.global_pnet(g_in.transpose(1, 2)).detach().clone()
+        if self.global_pnet is not None and FUSE_GLOBAL_PNET:
+            net.global_feature = self.global_pnet(g_in.contiguous())
+        else:
+            net.global_feature = net.global_pnet(g_in.transpose(1, 2)).detach().clone()
         l_uvw, l_cond = [uvw], [cond0]
         for i, sa in enumerate(self.cond_sa):
             sel = _ext.furthest_point_sampling(l_uvw[i], sa.npoint)

@@ -137,6 +137,47 @@ def test_groupnorm_fold_matches_torch_groupnorm(cuda):
     np.testing.assert_allclose(got.cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("remove_last", [False, True])
+def test_fused_global_pointnet_matches_the_torch_module(cuda, remove_last):
+    """VERDICT r3 missing 5: the global PointNet of a new batch (models/pnet.py; reference pnet.py:27-40) on the fused
+    layer kernels + pdr_act_colmax instead of torch Conv2d -> MIOpen, incl. the variant without the stages' last
+    GroupNorm / ReLU; and the condition / class embedding GEMMs of EmbeddingBank on pdr_embed_linear."""
+    from point_diffusion_refinement_amd.pointnet2.models.pnet import Pnet2Stage
+    torch.manual_seed(4)
+    pnet = fill_deterministic(Pnet2Stage([4, 128, 256], [512, 1024], bn=True, remove_last_activation=remove_last),
+                              17).eval().to(cuda)
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(3, 3072, 4, generator=g) * 2 - 1).to(cuda)
+    with torch.no_grad():
+        want = pnet(x.transpose(1, 2))
+        got = FN.FusedPnet2Stage(pnet)(x.contiguous())
+    assert got.shape == want.shape == (3, 1024)
+    from tests import parity
+    parity.check("fused_global_pointnet:%s" % ("conv_last" if remove_last else "gn_relu_last"), "hip", got, want, 1e-4)
+    # pdr_act_colmax alone: max over rows of relu(x s + t) + a
+    y = torch.randn(2 * 500, 70, generator=g).to(cuda)
+    sc, sh, ad = (torch.randn(2, 70, generator=g).to(cuda) for _ in range(3))
+    act = FN.Act([(y, 0, 70, 70, 1)], 1000, 2, 500, scale=sc, shift=sh, add=ad, add_ld=70, post_relu=True)
+    ref = ((y.view(2, 500, 70) * sc[:, None] + sh[:, None]).relu() + ad[:, None]).amax(1)
+    assert torch.equal(FN.act_colmax(act), ref) or float((FN.act_colmax(act) - ref).abs().max()) < 1e-6
+    # embedding rows of a new batch through pdr_embed_linear == F.linear
+    bank = FN.EmbeddingBank()
+    lin = [torch.nn.Linear(1024, 96).to(cuda), torch.nn.Linear(1024, 40).to(cuda)]
+    for m in lin:
+        bank.register("c", m)
+    bank.pack()
+    src = torch.randn(5, 1024, generator=g).to(cuda)
+    with torch.no_grad():
+        bank.evaluate_kind("c", src, static=True)
+        first = bank.out["c"]
+        ref = torch.cat([m(src) for m in lin], 1)
+        np.testing.assert_allclose(first.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+        bank.evaluate_kind("c", src * 0.5, static=True)                   # in place: same buffer, new contents
+        assert bank.out["c"].data_ptr() == first.data_ptr()
+        np.testing.assert_allclose(bank.out["c"].cpu().numpy(), torch.cat([m(src * 0.5) for m in lin], 1).cpu().numpy(),
+                                   rtol=2e-5, atol=2e-5)
+
+
 def _pair(cfg, seed, device):
     net = fill_deterministic(PointNet2CloudCondition(cfg), seed).eval().to(device)
     return net, FN.FusedCloudConditionNet(net)
@@ -269,6 +310,7 @@ _VARIANTS = [
     ("query_conv_unsplit", {"PDR_FUSED_OPTS": "SPLIT_QUERY_CONV=0"}, False),
     ("grouped_first_conv", {"PDR_FUSED_OPTS": "USE_SPLIT_FIRST=0"}, False),
     ("layerwise_condition_branch", {"PDR_FUSED_OPTS": "FUSE_CONDITION_BRANCH=0"}, False),
+    ("torch_global_pointnet", {"PDR_FUSED_OPTS": "FUSE_GLOBAL_PNET=0"}, False),
 ]
 
 
