@@ -1,6 +1,6 @@
 # end-of-round validation on the GPU box: full GPU suite, smoke, the driver's bench line, every profile artefact
-TAG=${1:-r3}
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${TAG}_pytest_gpu.txt
+TAG=${1:-r4}
+python -m pytest tests -m gpu -q --maxfail=10 2>&1 | tail -12 > gpurun_out/${TAG}_pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/${TAG}_smoke.txt
 python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1

@@ -18,7 +18,7 @@ from point_diffusion_refinement_amd.pointnet2.configs import synthetic_batch  # 
 def main():
     dev = torch.device("cuda:0")
     B = int(os.environ.get("MARK_B", "32"))
-    sampler, _ = build_sampler(dev, use_graph=True)
+    sampler, _ = build_sampler(dev, use_graph=True, precision=os.environ.get("MARK_PRECISION", "f32"))
     x_T, cond, label = synthetic_batch(B, seed=0, device=dev)
     buf = torch.zeros(512, dtype=torch.int64, device=dev)
     FN.MARKS = {"buf": buf, "names": [], "detail": os.environ.get("MARK_DETAIL", "0") == "1"}
@@ -43,7 +43,8 @@ def main():
     rel = (t - t[:, :1]) * 0.01                              # us after step:begin
     med = np.median(rel, axis=0)
     order = np.argsort(med, kind="stable") if not FN_DETAIL else np.arange(len(med))
-    out = {"batch": B, "replays": R, "unit": "us after step:begin (median of replays; 100 MHz clock)",
+    out = {"batch": B, "replays": R, "precision": os.environ.get("MARK_PRECISION", "f32"),
+           "unit": "us after step:begin (median of replays; 100 MHz clock)",
            "marks": [{"name": names[i], "median_us": float(med[i]), "min_us": float(rel[:, i].min()),
                       "max_us": float(rel[:, i].max())} for i in order]}
     # wall time of a replay by events for reference

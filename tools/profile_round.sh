@@ -8,7 +8,7 @@
 #   3. tools/op_roofline.py: FPS / ball_query / kNN / Chamfer / EMD at the BASELINE sizes, HIP-event timed
 #   4. tools/profile_summary.py -> <tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json, <tag>_mfma_util.json,
 #      <tag>_roofline.json
-TAG=${1:-r3}
+TAG=${1:-r4}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -38,6 +38,14 @@ python tools/op_roofline.py > $OUT/${TAG}_op_roofline.json 2> $OUT/${TAG}_op_roo
 # second file, inside every block
 python -m tools.lab.step_markers $OUT/${TAG}_timeline_markers.json > $OUT/${TAG}_timeline_markers.txt 2>&1
 MARK_DETAIL=1 python -m tools.lab.step_markers $OUT/${TAG}_timeline_markers_detail.json > /dev/null 2>&1
+# the same for the opt-in split-f16 step (is the FPS chain still hidden behind a shorter first block?)
+MARK_PRECISION=split_f16 python -m tools.lab.step_markers $OUT/${TAG}_timeline_markers_split.json > $OUT/${TAG}_timeline_markers_split.txt 2>&1
+# the once-per-batch first step by itself (no vendor kernels since round 4)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_first -o s -- python $REPO/tools/first_step_profile.py 32 > $OUT/${TAG}_first_step.log 2>&1 )
+cp $(find $OUT/${TAG}_first -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_first_step_kernel_stats.csv; rm -rf $OUT/${TAG}_first
+# clocks and power while the headline loop runs (what the 'implied clock' of the MFMA-utilisation table is about)
+( python bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1 & BP=$!
+  sleep 12; for i in 1 2 3 4 5 6; do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|mclk\|power" ; echo ---; sleep 0.4; done > $OUT/${TAG}_clocks_power.txt; wait $BP )
 python tools/profile_summary.py $OUT $TAG
 # raw counter dumps are large: keep only the summaries
 rm -rf $OUT/${TAG}_pmc $OUT/${TAG}_stats
