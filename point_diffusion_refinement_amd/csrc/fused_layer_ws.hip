@@ -36,6 +36,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // W quads: moved as 
 #ifdef PDR_LAB_TRACE
 // development probe (tools/lab): per-chunk timestamps of one consumer and one producer wave of one workgroup
 __device__ unsigned long long pdr_lab_trace[3][4096];
+// start / end (s_memrealtime, 100 MHz, one clock for the whole device) and XCC id of every workgroup of the last launch
+__device__ unsigned long long pdr_lab_wg[2048][3];
 #define PDR_T(role, slot)                                                                   \
   do {                                                                                      \
     if (trace_on && (threadIdx.x & 63) == 0 && (slot) < 4096)                               \
@@ -154,6 +156,14 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   // (XCD-local order with more workgroups per XCD than local tiles: nothing to do -- and the producers' first fetch
   // below must not run on a tile that does not exist)
   if (my_tiles == 0) return;
+#ifdef PDR_LAB_TRACE
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    pdr_lab_wg[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    pdr_lab_wg[blockIdx.x][2] = (xcc & 15) | (static_cast<unsigned long long>(my_tiles) << 8);
+  }
+#endif
   const int G = my_tiles * nch;
   const bool has_partial = partial != nullptr;
   if (tid == 0) epi_ticket = 0;       // ordered before its first use by the barrier B(0)
@@ -922,11 +932,17 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     PDR_T(0, 4 * g + 3);
     advance(cur);
   }
+#ifdef PDR_LAB_TRACE
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) pdr_lab_wg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 }  // namespace
 
 #ifdef PDR_LAB_TRACE
+extern "C" int pdr_lab_wg_read(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pdr_lab_wg), sizeof(unsigned long long) * 2048 * 3) == hipSuccess ? 0 : -1;
+}
 extern "C" int pdr_lab_trace_read(unsigned long long* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pdr_lab_trace), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
 }

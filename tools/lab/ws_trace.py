@@ -20,6 +20,25 @@ def main():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     buf = np.zeros((3, 4096), dtype=np.uint64)
     assert raw.pdr_lab_trace_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    if hasattr(raw, "pdr_lab_wg_read"):
+        wg = np.zeros((2048, 3), dtype=np.uint64)
+        assert raw.pdr_lab_wg_read(wg.ctypes.data_as(ctypes.c_void_p)) == 0
+        wg = wg[wg[:, 1] > 0].astype(np.int64)
+        t00 = wg[:, 0].min()
+        st, en, dur = (wg[:, 0] - t00) / 100.0, (wg[:, 1] - t00) / 100.0, (wg[:, 1] - wg[:, 0]) / 100.0
+        xcc, tiles = wg[:, 2] & 15, wg[:, 2] >> 8
+        q = lambda a: "min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" % (
+            a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max())
+        print("workgroups of the last launch (us on the 100 MHz device clock): %d, tiles each %d..%d" %
+              (len(wg), tiles.min(), tiles.max()))
+        print("  start    ", q(st))
+        print("  end      ", q(en))
+        print("  duration ", q(dur))
+        for x in range(8):
+            m = xcc == x
+            if m.any():
+                print("  XCC %d: %3d workgroups, start median %.1f, duration median %.1f max %.1f, last end %.1f" %
+                      (x, m.sum(), np.median(st[m]), np.median(dur[m]), dur[m].max(), en[m].max()))
     c = buf[0].reshape(-1, 4).astype(np.int64)
     p = buf[1].reshape(-1, 4).astype(np.int64)
     n = int((c[:, 0] > 0).sum())

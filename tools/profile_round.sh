@@ -44,8 +44,9 @@ MARK_PRECISION=split_f16 python -m tools.lab.step_markers $OUT/${TAG}_timeline_m
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_first -o s -- python $REPO/tools/first_step_profile.py 32 > $OUT/${TAG}_first_step.log 2>&1 )
 cp $(find $OUT/${TAG}_first -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_first_step_kernel_stats.csv; rm -rf $OUT/${TAG}_first
 # clocks and power while the headline loop runs (what the 'implied clock' of the MFMA-utilisation table is about)
-( python bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1 & BP=$!
-  sleep 12; for i in 1 2 3 4 5 6; do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|mclk\|power" ; echo ---; sleep 0.4; done > $OUT/${TAG}_clocks_power.txt; wait $BP )
+( python bench.py --steps 990 --warmup 5 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1 & BP=$!
+  # (990 timed steps = 8.6 s; sampled from process start: the loaded samples are the ones that count)
+  for i in $(seq 1 30); do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|power (W)" | tr '\n' ' '; echo; sleep 0.3; done > $OUT/${TAG}_clocks_power.txt; wait $BP )
 python tools/profile_summary.py $OUT $TAG
 # raw counter dumps are large: keep only the summaries
 rm -rf $OUT/${TAG}_pmc $OUT/${TAG}_stats

@@ -116,10 +116,13 @@ def main():
                "mfma_util": round(busy / (dur * 1e-9 * CLOCK_HZ * SIMDS), 4) if dur > 0 else None}
         cu = v["SQ_BUSY_CU_CYCLES"][0] / max(v["SQ_BUSY_CU_CYCLES"][1], 1)
         if cu > 0:
-            # SQ_BUSY_CU_CYCLES sums the busy cycles of the 256 CUs: busy / (4 SIMDs x that) is the matrix-pipe
-            # utilisation in ACTUAL shader cycles, and cu / 256 / duration the clock the kernel really ran at
+            # SQ_BUSY_CU_CYCLES sums the cycles in which a CU had at least one wave: busy / (4 SIMDs x that) is the
+            # matrix-pipe utilisation while a CU is occupied, and cu / (256 x duration x 2.4 GHz) the fraction of the
+            # kernel's duration the average CU is occupied at all (launch ramp, tail behind the slowest workgroup).
+            # Rounds 2-3 read the latter as a clock ("implied_clock_GHz"); tools/lab/clock_probe.hip and rocm-smi
+            # (profiles/r4_clock_probe.txt, r4_clocks_power.txt) show the chip at 2.39-2.40 GHz under this load.
             row["mfma_util_of_busy_cu_cycles"] = round(busy / (4.0 * cu), 4)
-            row["implied_clock_GHz"] = round(cu / 256.0 / dur, 3) if dur > 0 else None
+            row["cu_occupied_frac_of_kernel_time"] = round(cu / 256.0 / dur / (CLOCK_HZ * 1e-9), 3) if dur > 0 else None
         wc = v["SQ_WAVE_CYCLES"][0] / max(v["SQ_WAVE_CYCLES"][1], 1)
         if wc > 0:
             row["issue_stalled_frac_of_wave_cycles"] = round(v["SQ_WAIT_INST_ANY"][0] / max(v["SQ_WAIT_INST_ANY"][1], 1) / wc, 3)
@@ -128,16 +131,21 @@ def main():
         nv = v["SQ_INSTS_VALU"][0] / max(v["SQ_INSTS_VALU"][1], 1)
         nm = v["SQ_INSTS_VMEM_RD"][0] / max(v["SQ_INSTS_VMEM_RD"][1], 1)
         if nv > 0:
-            # wave-level instruction counts per launch: VALU issue time = 2 cycles each on a SIMD-32
+            # wave-level instruction counts per launch.  A VALU instruction is NOT hidden behind an fp32 MFMA: the
+            # SIMD issues one or the other (tools/lab/mfma_shadow.hip: +5.5-8.5 cycles per VALU instruction next to
+            # the wave's own MFMA stream, ~3 with two waves per SIMD) -- priced here at 4 cycles each
             row["valu_insts_per_launch"] = round(nv)
             row["vmem_rd_insts_per_launch"] = round(nm)
-            row["valu_issue_us_at_2p1GHz"] = round(nv * 2.0 / SIMDS / 2.1e9 * 1e6, 1)
+            row["valu_port_frac_of_kernel_time"] = round(nv * 4.0 / SIMDS / (dur * 1e-9 * CLOCK_HZ), 3) if dur > 0 else None
         mfma.append(row)
     mfma.sort(key=lambda r: -r["mfma_busy_cycles_per_launch"] * r["launches"])
     json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs); the fp32 "
                        "MFMA peak (157.3 TF) corresponds to 1.0.  mfma_util_of_busy_cu_cycles normalises by the "
-                       "cycles the CUs actually ran (SQ_BUSY_CU_CYCLES): the gap between the two is the clock "
-                       "the chip sustains under this load (implied_clock_GHz), not pipeline inefficiency",
+                       "cycles a CU holds at least one wave (SQ_BUSY_CU_CYCLES); cu_occupied_frac_of_kernel_time is "
+                       "that occupancy as a fraction of the launch's duration (ramp + tail behind the slowest "
+                       "workgroup; NOT a clock: the chip runs at 2.39-2.40 GHz under this load, "
+                       "profiles/r4_clock_probe.txt).  valu_port_frac_of_kernel_time prices every VALU instruction "
+                       "at 4 cycles of the SIMD's shared VALU / MFMA issue port (profiles/r4_mfma_shadow_probe.txt)",
                "kernels": mfma[:60]}, open(os.path.join(out, tag + "_mfma_util.json"), "w"), indent=1)
     # ---- roofline table
     tmap = {r["kernel"]: r for r in traffic}
