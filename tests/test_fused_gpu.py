@@ -984,3 +984,56 @@ def test_split_f16_network_and_sampler(cuda):
     # measured medians 6.5e-7 / 4.9e-6 (the second cloud carries a flipped near-tie, as clouds of the exact mode do)
     assert (per_cloud.median(1).values < 1e-4).all(), per_cloud.median(1).values
     assert int((per_cloud.max(1).values < 1e-3).sum()) >= 1 and float(per_cloud.max()) < 0.5, per_cloud.max(1).values
+
+
+@pytest.mark.parametrize("case", ["ball_empty_all", "ball_window", "ball_no_counts", "knn", "ragged_tile"])
+def test_gather_add_matches_torch(cuda, case):
+    """pdr_gather_add alone (the network tests only see it through whole blocks): Y = U[idx] + V (V0 for empty balls,
+    + d2 r1 + w r2 for the kNN form) bit for bit against torch, the per-tile GroupNorm moments (ReLU from relu_col0 on)
+    against float64; written column windows; a last tile of a cloud that is not full."""
+    import ctypes
+    from tools.lab.gather_add_bench import reference
+    rpb, K, Cout, n_src, has_em, has_s, relu_col0, win = {
+        "ball_empty_all": (1024, 32, 96, 300, True, False, 64, None),
+        "ball_window": (512, 32, 72, 128, True, False, 40, (8, 24)),
+        "ball_no_counts": (1024, 16, 160, 257, False, False, 0, None),
+        "knn": (640, 8, 44, 64, False, True, 44, None),
+        "ragged_tile": (1024 + 64, 32, 64, 99, True, False, 32, None),
+    }[case]
+    lib = _lib.load()
+    B, dev = 3, cuda
+    g = torch.Generator(device=dev).manual_seed(len(case))
+    P, ld = B * rpb, (Cout + 3) // 4 * 4
+    U = torch.randn(B * n_src + 1, ld, device=dev, generator=g)
+    V2 = torch.randn(P // K, 2 * ld, device=dev, generator=g)
+    idx = torch.randint(0, n_src, (P,), device=dev, dtype=torch.int32, generator=g)
+    cnt = torch.randint(0, 3, (P // K,), device=dev, dtype=torch.int32, generator=g) if has_em else None
+    s1 = torch.rand(P, device=dev, generator=g) if has_s else None
+    s2 = torch.rand(P, device=dev, generator=g) if has_s else None
+    r1 = torch.randn(ld + 4, device=dev, generator=g) if has_s else None
+    r2 = torch.randn(ld + 4, device=dev, generator=g) if has_s else None
+    tpb = (rpb + 127) // 128
+    partial = torch.full((B * tpb, Cout, 2), float("nan"), device=dev)
+    y0, yc = win if win else (0, -1)
+    Y = torch.full((P, (yc + 3) // 4 * 4 if win else ld), float("nan"), device=dev)
+    p = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib.pdr_gather_add(U.data_ptr(), ld, n_src, V2.data_ptr(), V2.data_ptr() + 4 * ld if has_em else None,
+                                  2 * ld, idx.data_ptr(), p(cnt), p(s1), p(r1), p(s2), p(r2), B, rpb, K, Cout,
+                                  Y.data_ptr(), Y.shape[1], partial.data_ptr(), relu_col0, y0, yc,
+                                  torch.cuda.current_stream().cuda_stream), "gather_add")
+    torch.cuda.synchronize()
+    # the tool's reference assumes whole tiles: evaluate it on rows padded per cloud to whole tiles for the moments
+    want, _ = reference(U, V2, ld, idx, cnt, s1, r1, s2, r2, B, rpb, K, Cout, n_src, relu_col0)
+    w = want[:, y0:y0 + (yc if win else Cout)]
+    if has_s:       # torch's addcmul need not contract like the kernel's fma: one rounding per term
+        assert ((Y[:, :w.shape[1]] - w).abs() <= 2e-6 * (w.abs() + 1)).all()
+    else:
+        assert torch.equal(Y[:, :w.shape[1]], w)
+    f = want.double()
+    f[:, relu_col0:] = f[:, relu_col0:].clamp_min(0)
+    f = f.view(B, rpb, Cout)
+    for t in range(tpb):
+        blk = f[:, t * 128:(t + 1) * 128]
+        wm = torch.stack([blk.sum(1), (blk * blk).sum(1)], -1)
+        got = partial.view(B, tpb, Cout, 2)[:, t].double()
+        assert ((got - wm).abs() <= 1e-4 * (wm.abs() + 1)).all(), (case, t)
