@@ -245,6 +245,15 @@ typedef struct {
   int oadd_div;         /* power of two */
   const float *gs1;     /* (P) per-position scalars of kNN-form gathered sources (see pdr_seg_t.g_r1), or NULL */
   const float *gs2;
+  /* A SUBSET of the row tiles (NULL: all of them): the launch computes the row tiles tile_list[0 .. *n_tiles)
+   * (row tile = b * tiles_per_batch + t, both in device memory: the subset is decided on the device, see
+   * pdr_dedup_plan) and neither reads nor writes the rows of any other tile.  Wave-specialised tile shapes only
+   * (PDR_EUNSUPPORTED otherwise). */
+  const int *tile_list;
+  const int *n_tiles;
+  int partial_tpb;      /* rows of `partial` per batch element (0 = tiles_per_batch): tile t of batch element b
+                         * writes row b * partial_tpb + t */
+  int reserved_;
 } pdr_layer_in_t;
 
 /* rows per workgroup tile chosen for `rows_per_batch` and `Cout` (256/128/64/32); a batch element is cut
@@ -355,6 +364,37 @@ int pdr_gather_add(const float *U, int ldu, int n_src, const float *V, const flo
                    const float *s2, const float *r2, int B, int rows_per_batch, int K, int Cout,
                    float *Y, int ldy, float *partial, int relu_col0, int ycol0, int ycols,
                    pdr_stream_t stream);
+
+/* ---- Neighbourhoods that are K copies of one row --------------------------------------
+ * ball_query pads a neighbourhood with its first hit (ball_query_gpu.cu:29-44), so a query with at most one point
+ * in its ball (an empty ball of a feature-transfer block is replaced by the query itself, pointnet2_utils.py:
+ * 387-401) contributes K identical rows to every per-neighbour tensor of its block.  pdr_dedup_plan marks the
+ * 128-row tiles all of whose queries are such copies; the block's per-neighbour launches skip them
+ * (pdr_layer_in_t.tile_list, pdr_gather_add_tiles) and a per-QUERY chain of the same layers supplies their
+ * GroupNorm moments (pdr_weighted_moments) and pooled rows (pdr_patch_rows).
+ *
+ * pdr_dedup_plan: idx (B,m,K) int32 / counts (B,m) of a ball query -> idx0 (B,m) first neighbours; row_w (B,m)
+ * float = K for the queries of skipped tiles, else 0; tile_valid (B*m*K/128) bytes; tile_list (same length: the
+ * valid row-tile numbers, ascending) and n_tiles (1).  K in {8,16,32}, m*K a multiple of 128. */
+int pdr_dedup_plan(const int *idx, const int *counts, int B, int m, int K, int *idx0, float *row_w,
+                   unsigned char *tile_valid, int *tile_list, int *n_tiles, pdr_stream_t stream);
+/* pdr_gather_add over the tiles with tile_valid[tile] != 0 only (the others are neither read nor written); tile t
+ * of batch element b writes row b * partial_tpb + t of `partial`. */
+int pdr_gather_add_tiles(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,
+                         const int *idx, const int *counts, const float *s1, const float *r1,
+                         const float *s2, const float *r2, int B, int rows_per_batch, int K, int Cout,
+                         float *Y, int ldy, float *partial, int relu_col0, int ycol0, int ycols,
+                         const unsigned char *tile_valid, int partial_tpb, pdr_stream_t stream);
+/* Moments of a materialised (B*rpb, C) tensor with one weight per row, appended to the moments of a tile subset:
+ * partial row b*ptpb + tpb_full + j  <-  sum_r w[r] f, sum_r w[r] f^2 over the rows r of 128-row tile j of batch
+ * element b (f = y, columns >= relu_col0: max(y,0)); partial rows b*ptpb + t (t < tpb_full) of the tiles with
+ * tile_valid[b*tpb_full + t] == 0  <-  0.  ptpb >= tpb_full + ceil(rpb/128). */
+int pdr_weighted_moments(const float *Y, int ldy, int B, int rpb, int C, int relu_col0, const float *row_w,
+                         float *partial, int ptpb, int tpb_full, const unsigned char *tile_valid,
+                         pdr_stream_t stream);
+/* out[q,:D] = act(V[q,:D] * vscale[b] + vshift[b]) for the rows q with row_w[q] > 0; other rows untouched. */
+int pdr_patch_rows(const float *V, int ldv, const float *vscale, const float *vshift, int v_relu,
+                   const float *row_w, int B, int rpb, int D, float *out, int ldo, pdr_stream_t stream);
 /* out (B,m,C) = src (B,n,C)[idx (B,m)] */
 int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m, float *out,
                     pdr_stream_t stream);

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
     const float* __restrict__ s1, const float* __restrict__ r1, const float* __restrict__ s2,
     const float* __restrict__ r2, int rows_per_batch, int K, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int ycol0, int ycol1) {
+    float* __restrict__ partial, int relu_col0, int ycol0, int ycol1,
+    const unsigned char* __restrict__ tile_valid, int partial_tpb) {
   constexpr int TM = 128;
   constexpr int RPI = 64 / LPR;            // rows per wave instruction
   // row groups in flight per iteration: the kernel is bound by the latency of its L2 gathers, so every wave keeps
@@ -427,6 +428,9 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
   const int tpb = (rows_per_batch + TM - 1) / TM;
   const int bid = pdr::xcd_contiguous(blockIdx.x, gridDim.x);
   const int b = bid / tpb, tb = bid - b * tpb;
+  // a tile subset (pdr_dedup_plan): the other tiles are neither read nor written
+  if (tile_valid && !tile_valid[bid]) return;   // uniform
+  const long prow = static_cast<long>(b) * (partial_tpb > 0 ? partial_tpb : tpb) + tb;   // the tile's partial row
   const long row0 = static_cast<long>(b) * rows_per_batch + static_cast<long>(tb) * TM;
   const int nvalid = min(TM, rows_per_batch - tb * TM);
   const float* Ub = U + static_cast<long>(b) * n_src * ldu;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
                          (red[2][threadIdx.x][0] + red[3][threadIdx.x][0]);
         const float t2 = (red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) +
                          (red[2][threadIdx.x][1] + red[3][threadIdx.x][1]);
-        float* o = partial + (static_cast<long>(bid) * Cout + cc2) * 2;
+        float* o = partial + (prow * Cout + cc2) * 2;
         o[0] = t1;
         o[1] = t2;
       }
@@ -545,11 +549,12 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
 // Y (B*rows_per_batch, Cout; ld ldy) = U[b, idx[p]] + V[p / K] (+ s1[p] r1 + s2[p] r2), empty balls -> V0.
 // U (B, n_src, ldu), V / V0 (B*rows_per_batch/K, ldv); all leading dimensions multiples of 4, 16-B
 // aligned.  partial: NULL or (B * ceil(rows_per_batch / 128), Cout, 2) moments as in pdr_fused_layer.
-extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V, const float* V0,
-                              int ldv, const int* idx, const int* counts, const float* s1,
-                              const float* r1, const float* s2, const float* r2, int B,
-                              int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
-                              int relu_col0, int ycol0, int ycols, pdr_stream_t stream) {
+static int gather_add_impl(const float* U, int ldu, int n_src, const float* V, const float* V0,
+                           int ldv, const int* idx, const int* counts, const float* s1,
+                           const float* r1, const float* s2, const float* r2, int B,
+                           int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
+                           int relu_col0, int ycol0, int ycols, const unsigned char* tile_valid, int partial_tpb,
+                           pdr_stream_t stream) {
   if (!U || !V || !idx || (!Y && !partial) || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 ||
       n_src <= 0)
     return PDR_EINVAL;
@@ -573,7 +578,7 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
 #define PDR_GA_K(LPR, KP, HS)                                                                          \
   hipLaunchKernelGGL((gather_add_kernel<LPR, KP, HS>), grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
                      counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0, ycol0, \
-                     ycol0 + y4)
+                     ycol0 + y4, tile_valid, partial_tpb)
 #define PDR_GA(LPR)                                       \
   do {                                                    \
     if (kpow2 && has_s) PDR_GA_K(LPR, true, true);        \
@@ -586,5 +591,206 @@ extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V
   else PDR_GA(64);
 #undef PDR_GA
 #undef PDR_GA_K
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_gather_add(const float* U, int ldu, int n_src, const float* V, const float* V0,
+                              int ldv, const int* idx, const int* counts, const float* s1,
+                              const float* r1, const float* s2, const float* r2, int B,
+                              int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
+                              int relu_col0, int ycol0, int ycols, pdr_stream_t stream) {
+  return gather_add_impl(U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2, B, rows_per_batch, K, Cout, Y, ldy,
+                         partial, relu_col0, ycol0, ycols, nullptr, 0, stream);
+}
+
+// pdr_gather_add over a SUBSET of its 128-row tiles: tile_valid (B * ceil(rows_per_batch / 128)) bytes from
+// pdr_dedup_plan, tiles with a zero byte are neither read nor written; tile t of batch element b writes row
+// b * partial_tpb + t of `partial` (partial_tpb >= tiles per batch element).
+extern "C" int pdr_gather_add_tiles(const float* U, int ldu, int n_src, const float* V, const float* V0,
+                                    int ldv, const int* idx, const int* counts, const float* s1,
+                                    const float* r1, const float* s2, const float* r2, int B,
+                                    int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
+                                    int relu_col0, int ycol0, int ycols, const unsigned char* tile_valid,
+                                    int partial_tpb, pdr_stream_t stream) {
+  if (!tile_valid || partial_tpb < (rows_per_batch + 127) / 128) return PDR_EINVAL;
+  return gather_add_impl(U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2, B, rows_per_batch, K, Cout, Y, ldy,
+                         partial, relu_col0, ycol0, ycols, tile_valid, partial_tpb, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Neighbourhoods that are 32 copies of one row.
+//
+// ball_query pads a neighbourhood with its first hit; a query with at most ONE neighbour in its ball (count <= 1; an
+// empty ball of a feature-transfer block is replaced by the query itself) therefore contributes K identical rows to
+// every per-neighbour tensor of its block: the convs repeat one row K times, the attention pooling returns that row's
+// value (one unmasked slot), the GroupNorm moments count it K times.  On x_t of a reverse process (noise for most of
+// the trajectory) that is the rule, not the exception.  pdr_dedup_plan marks the 128-row tiles (128 / K queries)
+// ALL of whose queries are such copies; the block's per-neighbour launches skip them (pdr_layer_in_t.tile_list,
+// pdr_gather_add_tiles) and a K times smaller per-QUERY chain of the same layers supplies their moments
+// (pdr_weighted_moments) and their pooled rows (pdr_patch_rows).  Same values as the full evaluation up to fp32
+// summation order of the moments.
+// (1) per tile, in parallel: the valid flag, its queries' weights and first neighbours
+__global__ __launch_bounds__(256) void dedup_flags_kernel(const int* __restrict__ idx, const int* __restrict__ counts,
+                                                          int K, long nq, int qpt, int* __restrict__ idx0,
+                                                          float* __restrict__ row_w,
+                                                          unsigned char* __restrict__ tile_valid) {
+  const long q = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;   // 256 / qpt whole tiles per workgroup
+  if (q >= nq) return;
+  const int cnt = counts[q];
+  idx0[q] = idx[q * K];
+  // a tile's qpt (2 .. 16, a power of two) queries sit in consecutive lanes of one wave
+  int v = cnt > 1 ? 1 : 0;
+  for (int off = 1; off < qpt; off <<= 1) v |= __shfl_xor(v, off, 64);   // (every lane takes part in every exchange)
+  const bool valid = v != 0;
+  row_w[q] = valid ? 0.0f : static_cast<float>(K);
+  if ((q & (qpt - 1)) == 0) tile_valid[q / qpt] = valid ? 1 : 0;
+}
+
+// (2) ONE workgroup: ordered compaction of the valid tile numbers (ballot prefix per wave, wave totals through LDS,
+// chunks of 1024 tiles in ascending order)
+__global__ __launch_bounds__(1024) void dedup_compact_kernel(const unsigned char* __restrict__ tile_valid, int ntiles,
+                                                            int* __restrict__ tile_list, int* __restrict__ n_tiles) {
+  __shared__ int wtot[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < ntiles; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool valid = i < ntiles && tile_valid[i] != 0;
+    const unsigned long long bal = __ballot(valid);
+    const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      woff += w < wave ? wtot[w] : 0;
+      tot += wtot[w];
+    }
+    const int base = base_s;
+    if (valid) tile_list[base + woff + before] = i;
+    __syncthreads();
+    if (tid == 0) base_s = base + tot;
+    __syncthreads();
+  }
+  if (tid == 0) *n_tiles = base_s;
+}
+
+// idx (B, m, K) int32 / counts (B, m) of a ball query ->
+//   idx0 (B, m): the first neighbour of every query;  row_w (B, m) float: K for the queries of skipped tiles, else 0;
+//   tile_valid (B * m K / 128) bytes, tile_list (same length, the valid tile numbers in ascending order), n_tiles (1).
+// A tile = 128 rows = 128 / K queries is VALID (computed by the per-neighbour launches) when any of its queries has
+// more than one neighbour.  K in {8, 16, 32}, m K a multiple of 128.
+extern "C" int pdr_dedup_plan(const int* idx, const int* counts, int B, int m, int K, int* idx0, float* row_w,
+                              unsigned char* tile_valid, int* tile_list, int* n_tiles, pdr_stream_t stream) {
+  if (!idx || !counts || !idx0 || !row_w || !tile_valid || !tile_list || !n_tiles || B < 0 || m <= 0) return PDR_EINVAL;
+  if (!(K == 8 || K == 16 || K == 32) || (static_cast<long>(m) * K) % 128 != 0) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  const int qpt = 128 / K;
+  const long ntiles = static_cast<long>(B) * m / qpt;
+  if (ntiles >= (1L << 30)) return PDR_EINVAL;
+  const long nq = static_cast<long>(B) * m;
+  hipLaunchKernelGGL(dedup_flags_kernel, dim3(blocks_for(nq)), dim3(256), 0, pdr::as_stream(stream), idx, counts, K, nq,
+                     qpt, idx0, row_w, tile_valid);
+  hipLaunchKernelGGL(dedup_compact_kernel, dim3(1), dim3(1024), 0, pdr::as_stream(stream), tile_valid,
+                     static_cast<int>(ntiles), tile_list, n_tiles);
+  return pdr::check_launch();
+}
+
+// Per-tile GroupNorm moments of a materialised (B rpb, C) tensor with one WEIGHT per row, written behind the
+// moments of a tile subset: block (j, cy) handles rows [128 j, 128 j + 128) of batch element b = j / tpbd and 64
+// columns; the trailing blocks zero the partial rows of the tiles the subset skipped.
+__global__ __launch_bounds__(256) void weighted_moments_kernel(const float* __restrict__ Y, int ldy, int C, int rpb,
+                                                               int tpbd, int nB, int relu_col0,
+                                                               const float* __restrict__ row_w,
+                                                               float* __restrict__ partial, int ptpb, int tpb_full,
+                                                               const unsigned char* __restrict__ tile_valid) {
+  const int nmom = nB * tpbd;
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  if (static_cast<int>(blockIdx.x) >= nmom) {
+    // zero the rows of skipped tiles: 16 tiles per block, this block's 64 columns
+    const int t0 = (static_cast<int>(blockIdx.x) - nmom) * 16;
+    for (int k = sl; k < 16; k += 4) {
+      const int t = t0 + k;
+      if (t < nB * tpb_full && !tile_valid[t] && c < C) {
+        const int b = t / tpb_full, tb = t - b * tpb_full;
+        float* o = partial + ((static_cast<long>(b) * ptpb + tb) * C + c) * 2;
+        o[0] = 0.0f;
+        o[1] = 0.0f;
+      }
+    }
+    return;
+  }
+  __shared__ float red[4][64][2];
+  const int b = blockIdx.x / tpbd, j = blockIdx.x - b * tpbd;
+  const int r0 = j * 128 + sl * 32, r1 = min(r0 + 32, rpb);
+  float s1 = 0.0f, s2 = 0.0f;
+  if (c < C) {
+    const float lo = c >= relu_col0 ? 0.0f : -__builtin_inff();
+    const float* yp = Y + (static_cast<long>(b) * rpb) * ldy + c;
+    const float* wp = row_w + static_cast<long>(b) * rpb;
+    for (int r = r0; r < r1; ++r) {
+      const float f = fmaxf(yp[static_cast<long>(r) * ldy], lo);
+      const float w = wp[r];
+      s1 = __builtin_fmaf(w, f, s1);
+      s2 = __builtin_fmaf(w * f, f, s2);
+    }
+  }
+  red[sl][cl][0] = s1;
+  red[sl][cl][1] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float* o = partial + ((static_cast<long>(b) * ptpb + tpb_full + j) * C + c) * 2;
+    o[0] = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+    o[1] = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+  }
+}
+
+// partial (B * ptpb, C, 2): rows [b ptpb + tpb_full + j] (j < ceil(rpb / 128)) <- sum_r w[r] f, sum_r w[r] f^2 over the
+// rows of tile j of Y (B rpb, C; ld ldy), f = y (columns >= relu_col0: max(y, 0)); rows [b ptpb + t] of the tiles
+// t < tpb_full with tile_valid[b tpb_full + t] == 0 <- 0.  ptpb >= tpb_full + ceil(rpb / 128).
+extern "C" int pdr_weighted_moments(const float* Y, int ldy, int B, int rpb, int C, int relu_col0, const float* row_w,
+                                    float* partial, int ptpb, int tpb_full, const unsigned char* tile_valid,
+                                    pdr_stream_t stream) {
+  if (!Y || !row_w || !partial || !tile_valid || B < 0 || rpb <= 0 || C <= 0 || ldy < C || tpb_full <= 0) return PDR_EINVAL;
+  const int tpbd = (rpb + 127) / 128;
+  if (ptpb < tpb_full + tpbd) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  const long nz = (static_cast<long>(B) * tpb_full + 15) / 16;
+  const dim3 grid(static_cast<unsigned>(static_cast<long>(B) * tpbd + nz), static_cast<unsigned>((C + 63) / 64));
+  hipLaunchKernelGGL(weighted_moments_kernel, grid, dim3(256), 0, pdr::as_stream(stream), Y, ldy, C, rpb, tpbd, B,
+                     relu_col0, row_w, partial, ptpb, tpb_full, tile_valid);
+  return pdr::check_launch();
+}
+
+// out[q, :D] = act(V[q, :D] * vscale[b] + vshift[b]) for the rows q with row_w[q] > 0 (the pooled output of a query
+// whose neighbourhood is K copies of one row is that row's activated value); other rows untouched.
+__global__ __launch_bounds__(256) void patch_rows_kernel(const float* __restrict__ V, int ldv,
+                                                         const float* __restrict__ vscale,
+                                                         const float* __restrict__ vshift, int v_relu,
+                                                         const float* __restrict__ row_w, int rpb, int D, long total,
+                                                         float* __restrict__ out, int ldo) {
+  const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long q = e / D;
+  const int d = static_cast<int>(e - q * D);
+  if (!(row_w[q] > 0.0f)) return;
+  const long b = q / rpb;
+  float v = V[q * ldv + d];
+  const float s = vscale ? vscale[b * D + d] : 1.0f;
+  const float h = vshift ? vshift[b * D + d] : 0.0f;
+  v = __builtin_fmaf(v, s, h);
+  if (v_relu) v = fmaxf(v, 0.0f);
+  out[q * ldo + d] = v;
+}
+
+extern "C" int pdr_patch_rows(const float* V, int ldv, const float* vscale, const float* vshift, int v_relu,
+                              const float* row_w, int B, int rpb, int D, float* out, int ldo, pdr_stream_t stream) {
+  if (!V || !row_w || !out || B < 0 || rpb <= 0 || D <= 0 || ldv < D || ldo < D) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  const long total = static_cast<long>(B) * rpb * D;
+  hipLaunchKernelGGL(patch_rows_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream), V, ldv, vscale,
+                     vshift, v_relu, row_w, rpb, D, total, out, ldo);
   return pdr::check_launch();
 }

@@ -1046,7 +1046,9 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   if (gx > cap) gx = cap;
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
   const int nt = static_cast<int>(ntiles);
-  if (pl.thin && !partial) {
+  // a tile subset (pdr_layer_in_t.tile_list) is walked by the wave-specialised kernels with 128-row tiles only
+  if (in->tile_list && (!in->n_tiles || !pl.ws || t.tm != 128)) return PDR_EUNSUPPORTED;
+  if (pl.thin && !partial && !in->tile_list) {
     const int c4n = (Cout + 3) / 4;
     int qshift = 3;                                    // 8 .. 64 column quads per row of threads
     while (qshift < 6 && (1 << qshift) < c4n) ++qshift;
@@ -1062,7 +1064,7 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
                                  ncol, s))
     return pdr::check_launch();
   // kNN-form gathered sources exist in the wave-specialised kernel only: the caller materialises instead
-  if (pl.knn) return PDR_EUNSUPPORTED;
+  if (pl.knn || in->tile_list) return PDR_EUNSUPPORTED;
 #define PDR_LAUNCH_V(RT, CT, WR, WC, KC, RADD, VEC, GATH)                                            \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, RADD, VEC, GATH>), grid, dim3(256), 0, s, \
                      *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt)
@@ -1148,6 +1150,7 @@ extern "C" int pdr_fused_layer_pool_f16x3(const pdr_layer_in_t* in, long P, int 
   if (!vec || !use_ws_kernels()) return PDR_EUNSUPPORTED;
   const TileCfg t = pick_tile(in->rows_per_batch, D);
   if ((t.id != 4 && t.id != 5 && t.id != 8) || in->rows_per_batch % t.tm != 0) return PDR_EUNSUPPORTED;
+  if (in->tile_list && (!in->n_tiles || t.tm != 128)) return PDR_EUNSUPPORTED;
   const long nb = P / in->rows_per_batch;
   const long ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
   const int ncol = (D + t.tn - 1) / t.tn;
@@ -1181,6 +1184,7 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
     return PDR_EINVAL;
   if (!vec) return PDR_EUNSUPPORTED;
   const TileCfg t = pick_tile(in->rows_per_batch, D);
+  if (in->tile_list && (!in->n_tiles || t.tm != 128)) return PDR_EUNSUPPORTED;
   hipStream_t s = pdr::as_stream(stream);
   const long nb = P / in->rows_per_batch;
   const long ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
@@ -1196,6 +1200,7 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
       pdr::launch_fused_layer_ws(t.id, false, false, *in, Cin, Wt, ldw, bias, D, nullptr, 0, nullptr, D, nt, ncol, s,
                                  false, &pa))
     return pdr::check_launch();
+  if (in->tile_list) return PDR_EUNSUPPORTED;   // tile subsets: wave-specialised kernels only
 #define PDR_LAUNCH_P(RT, CT, WR, WC, KC)                                                              \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false, true, false, true>), grid, dim3(256), \
                      0, s, *in, Cin, Wt, ldw, bias, D, static_cast<float*>(nullptr), 0,                   \

@@ -146,11 +146,20 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   const int nwg = static_cast<int>(gridDim.x);
   const int nB = n_row_tiles / tpb;
   // (whole groups of 8 clouds only: otherwise some XCDs would own fewer clouds than others)
-  const bool xcd_order = tile_order != 0 && (nwg & 7) == 0 && nB >= 8 && (nB & 7) == 0;   // uniform
+  //   listed     (in.tile_list, round 4): the launch computes only the row tiles tile_list[0 .. *n_tiles) -- the tiles of
+  //              a grouped block whose 32-row neighbourhoods are not all copies of their first row;
+  //              local tile l = list entry l, plain strided walk over the list; every other tile is neither read nor
+  //              written (its rows of Y / partial keep whatever they held).
+  const bool listed = in.tile_list != nullptr;                                            // uniform
+  const bool xcd_order = !listed && tile_order != 0 && (nwg & 7) == 0 && nB >= 8 && (nB & 7) == 0;   // uniform
   const int xcd = static_cast<int>(blockIdx.x) & 7;
   const int tile_first = xcd_order ? static_cast<int>(blockIdx.x) >> 3 : static_cast<int>(blockIdx.x);
   const int tile_step = xcd_order ? nwg >> 3 : nwg;
-  const int tile_limit = xcd_order ? ((nB - xcd + 7) >> 3) * tpb : n_row_tiles;   // local tiles of this walk
+  const int tile_limit = listed ? min(*in.n_tiles, n_row_tiles)
+                                : (xcd_order ? ((nB - xcd + 7) >> 3) * tpb : n_row_tiles);   // local tiles of this walk
+  // local tile number -> row tile (listed: one scalar load; the list is a few KB, read by every workgroup)
+  auto row_tile = [&](int l) __attribute__((always_inline)) -> int { return listed ? in.tile_list[l] : l; };
+  const int ptpb = in.partial_tpb > 0 ? in.partial_tpb : tpb;   // rows of `partial` per batch element
   const int cloud_mul = xcd_order ? 8 : 1, cloud_add = xcd_order ? xcd : 0;
   const int my_tiles = tile_limit > tile_first ? (tile_limit - tile_first + tile_step - 1) / tile_step : 0;
   // (XCD-local order with more workgroups per XCD than local tiles: nothing to do -- and the producers' first fetch
@@ -280,7 +289,8 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     int Rkmax = KC, Rcvalid = 4;   // valid k rows of the chunk; valid channels of this thread's float4
     // fetch: chunk at cursor c -> registers (address arithmetic + loads only)
     auto fetch = [&](const Cur& c) __attribute__((always_inline)) {
-      const int bl = c.tile / tpb, tb = c.tile - bl * tpb;
+      const int lt = row_tile(c.tile);
+      const int bl = lt / tpb, tb = lt - bl * tpb;
       const int b = bl * cloud_mul + cloud_add;
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
@@ -324,7 +334,8 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
         }
         const int nt = c.tile + tile_step;
         if (GATH == 1 && last_of_tile(c) && nt < tile_limit) {  // uniform: prefetch the next tile's indices
-          const int nbl = nt / tpb, ntb = nt - nbl * tpb;
+          const int nlt = row_tile(nt);
+          const int nbl = nlt / tpb, ntb = nlt - nbl * tpb;
           const int nb = nbl * cloud_mul + cloud_add;
           const long nrow0 = static_cast<long>(nb) * rpb + static_cast<long>(ntb) * TM;
           const int nnv = min(TM, rpb - ntb * TM);
@@ -669,9 +680,10 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     PDR_T(0, 4 * g + 2);
     if (last_of_tile(cur)) {
       // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)
-      const int bl = cur.tile / tpb, tb = cur.tile - bl * tpb;
+      const int lt = row_tile(cur.tile);
+      const int bl = lt / tpb, tb = lt - bl * tpb;
       const int b = bl * cloud_mul + cloud_add;
-      const int tile = b * tpb + tb;           // row tile (index of its partial row)
+      const int tile = b * ptpb + tb;          // index of the tile's partial row
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
       const bool rows_full = nvalid == TM;   // uniform

@@ -77,6 +77,13 @@ FUSE_GLOBAL_PNET = True
 # the geometry stream or the blocks' second-half stream at HIP priority -1 beside normal-priority streams 11.5-12.0 ms
 # per step vs 8.75 -- kernels of different priorities no longer overlap; both at -1: 8.81-8.85; not used.)
 LAB_SKIP_FOLD = False
+# Neighbourhoods that are K copies of one row (ball_query pads with the first hit; a query with <= 1 point in its ball,
+# the rule on x_t for most of a reverse process) are evaluated ONCE: the per-neighbour launches of a grouped block walk
+# only the 128-row tiles that contain a real neighbourhood (pdr_dedup_plan), a per-QUERY chain of the same layers
+# supplies the moments (x K) and the pooled rows of the others.  DESIGN.md section 4.7.  Blocks with fewer queries per
+# cloud than DEDUP_MIN_QUERIES run whole (their launches are latency-bound already).
+DEDUP = True
+DEDUP_MIN_QUERIES = 256
 
 
 def _stream():
@@ -87,6 +94,13 @@ def _stream():
 # mark(name) launches pdr_mark_time on the CURRENT stream; capturable, so the stamps of an untraced graph replay
 # can be read back afterwards.  None = no launches (the default).
 MARKS = None
+TAPS = None          # lab: list collecting (name, tensor clone) when set
+
+
+def _tap(name, t):
+    if TAPS is not None and t is not None:
+        TAPS.append((name, t.detach().clone()))
+
 
 
 def mark(name, detail=False):
@@ -134,6 +148,16 @@ class Act:
         self.first = None              # the FirstOut the gathered segments come from (fallback: materialise)
         self.ss_ld = 0                 # leading dimension of scale / shift (0 = C)
         self.oadd = None               # (tensor (rows, ld), div): output-side per-query add
+        self.dd = None                 # Dedup plan of the block: the launch walks its tile subset
+        self.twin = None               # the same activation over the block's per-QUERY rows (first neighbour only)
+
+    _SHARED = ("scale", "shift", "add", "add_ld", "pre_relu", "post_relu", "ss_ld")
+
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+        tw = self.__dict__.get("twin")
+        if tw is not None and k in Act._SHARED:            # the prologue is the same for both row sets
+            object.__setattr__(tw, k, v)
 
     def struct(self):
         li = _lib.LayerIn()
@@ -156,7 +180,47 @@ class Act:
             li.gK = self.gK
             if self.gs1 is not None:
                 li.gs1, li.gs2 = self.gs1.data_ptr(), self.gs2.data_ptr()
+        if self.dd is not None:
+            li.tile_list, li.n_tiles = self.dd.tile_list.data_ptr(), self.dd.n_tiles.data_ptr()
+            li.partial_tpb = self.dd.ptpb
         return li
+
+
+class Dedup:
+    """Plan of one grouped block's per-neighbour launches (pdr_dedup_plan): which 128-row tiles hold a real
+    neighbourhood, the weights / first neighbours of the per-query chain that stands in for the others."""
+
+    def __init__(self, idx, counts, B, m, K):
+        dev = idx.device
+        self.B, self.m, self.K = B, m, K
+        self.tpb, self.tpbd = m * K // 128, (m + 127) // 128
+        self.ptpb = self.tpb + self.tpbd                       # partial rows per cloud: [tiles | per-query tiles]
+        nt = B * self.tpb
+        self.idx0 = torch.empty((B, m), dtype=torch.int32, device=dev)
+        self.row_w = torch.empty((B * m,), dtype=torch.float32, device=dev)
+        self.tile_valid = torch.empty((nt,), dtype=torch.uint8, device=dev)
+        self.tile_list = torch.empty((nt,), dtype=torch.int32, device=dev)
+        self.n_tiles = torch.empty((1,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().pdr_dedup_plan(idx.data_ptr(), counts.data_ptr(), B, m, K, self.idx0.data_ptr(),
+                                              self.row_w.data_ptr(), self.tile_valid.data_ptr(),
+                                              self.tile_list.data_ptr(), self.n_tiles.data_ptr(), _stream()),
+                   "dedup_plan")
+
+    def moments(self, Yd, C, relu_col0, partial):
+        """Weighted moments of the per-query rows behind the tile subset's, zeros for the skipped tiles."""
+        _lib.check(_lib.load().pdr_weighted_moments(Yd.data_ptr(), Yd.shape[1], self.B, self.m, C, relu_col0,
+                                                    self.row_w.data_ptr(), partial.data_ptr(), self.ptpb, self.tpb,
+                                                    self.tile_valid.data_ptr(), _stream()), "weighted_moments")
+
+
+def act_from(Y, C, P, B, rpb, **kw):
+    """Act over the first C columns of a layer output (with its per-query twin when the layer ran deduplicated)."""
+    a = Act([(Y, 0, C, Y.shape[1], 1)], P, B, rpb, **kw)
+    dd = getattr(Y, "_dd", None)
+    if dd is not None:
+        a.dd = dd
+        a.twin = Act([(Y._twin, 0, C, Y._twin.shape[1], 1)], dd.B * dd.m, B, dd.m, **kw)
+    return a
 
 
 class FirstOut:
@@ -172,6 +236,7 @@ class FirstOut:
         self.Yres, self.res_col0, self.res_cols = Yres, res_col0, res_cols
         self.s1, self.s2, self.r1, self.r2 = s1, s2, r1, r2          # kNN form (r1 / r2: padded conv rows)
         self.materialise = materialise                                # (col0, C) -> (P, pad4(C)) tensor
+        self.dd, self.deg = None, None      # Dedup plan + the first conv of the per-query rows (B m, ld), materialised
 
     @property
     def virtual(self):
@@ -192,6 +257,19 @@ class FirstOut:
         if self.virtual:
             act.gidx, act.gcnt, act.gK = self.idx, self.counts, self.K
             act.gs1, act.gs2, act.first = self.s1, self.s2, self
+        if self.dd is not None:
+            dd, Yd = self.dd, self.deg
+            if act.twin is None:
+                # the activation reads this first conv: its twin reads the same columns of the per-query rows
+                if len(act.segs) != 1 or len(act.segs[0]) <= 5:
+                    raise NotImplementedError("deduplicated block: one gathered source per layer")
+                _, col0, C = act.segs[0][:3]
+                tw = Act([(Yd, col0, C, Yd.shape[1], 1)], dd.B * dd.m, act.B, dd.m)
+                for k in Act._SHARED:
+                    object.__setattr__(tw, k, getattr(act, k))
+                act.dd, act.twin = dd, tw
+            if act.radd is not None and len(act.radd) > 5:      # gathered residual window
+                act.twin.radd = (Yd, act.radd[1], act.radd[2], Yd.shape[1], 1)
         return act
 
 
@@ -412,6 +490,10 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
         y_ptr = Y.data_ptr()
     tm = lib.pdr_fused_layer_tile_rows(act.rpb, conv.Cout)
     tpb = (act.rpb + tm - 1) // tm
+    dd = act.dd
+    if dd is not None:
+        assert tm == 128 and tpb == dd.tpb and out is None and not extra_rows, (tm, tpb, dd.tpb)
+        tpb = dd.ptpb                   # rows of `partial` per cloud: the tile subset's + the per-query rows'
     partial = None
     stats = stats or fold is not None
     if stats:
@@ -438,6 +520,13 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
                                      conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
                                      partial.data_ptr() if stats else None, rc0, _stream())
         _lib.check(rc, "fused_layer")
+    if dd is not None and act.twin is not None:
+        # the same layer over the per-query rows (first neighbour of every query): its rows stand for the K copies
+        # in the skipped tiles -- moments weighted by K there, 0 elsewhere
+        Yd = run_layer(act.twin, conv, relu_col0=relu_col0)[0]
+        if stats:
+            dd.moments(Yd, conv.Cout, rc0, partial)
+        Y._twin, Y._dd = Yd, dd
     if fold is None:
         return Y, partial, tpb
     return Y, partial, tpb, fold.launch(partial, tpb, act.B)
@@ -484,6 +573,8 @@ class Norm:
                                    scale.data_ptr(), shift.data_ptr(), _stream()), "gn_fold")
         if LAB_SKIP_FOLD:
             self._lab_fold[(B, C, n)] = (scale, shift)
+        _tap("fold_scale", scale)
+        _tap("fold_shift", shift)
         return scale, shift
 
 
@@ -627,7 +718,7 @@ class FusedMlp:
             if i < len(self.rest):
                 Y, part, tpb, folded = run_layer(cur, self.rest[i],
                                                  fold=FoldReq(self.norms[i + 1], self.rest[i].Cout, rpb))
-                cur = Act([(Y, 0, self.rest[i].Cout, Y.shape[1], 1)], P, B, rpb)
+                cur = act_from(Y, self.rest[i].Cout, P, B, rpb)
         if self.has_res:
             if self.res_col0 is not None:
                 cur.radd = first.seg(self.res_col0, self.Clast)
@@ -692,6 +783,8 @@ class FusedAttention:
                                  shift=t[:, self.C1:], pre_relu=True))
             a.ss_ld = Ct
             a.oadd = (Z, K)
+            if a.twin is not None:
+                a.twin.oadd = (Z, 1)                 # per-query rows: one row per query of Z
             S1, _, _, (s, t) = run_layer(a, self.w1_k, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
         else:
             a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B,
@@ -699,12 +792,24 @@ class FusedAttention:
             S1, _, _, (s, t) = run_layer(a, self.w1, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
         mark("  blk:main_scores_ready", True)
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
+        dd = getattr(S1, "_dd", None)
+        score_in.dd = dd                             # the pooled launch walks the block's tile subset
         # (a callable: the value half runs on another stream; calling it joins that stream into this one)
         V, vs, vt = values() if callable(values) else (values if values is not None else self.values(h, B, npoint, K))
         mark("  blk:joined", True)
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
         cptr = counts.data_ptr() if counts is not None else None
         vsp, vtp = (vs.data_ptr(), vt.data_ptr()) if vs is not None else (None, None)
+
+        def patch():
+            # queries of the skipped tiles: one unmasked neighbour, i.e. the pooled row is its activated value row
+            if dd is not None:
+                Vd = V._twin
+                _lib.check(lib.pdr_patch_rows(Vd.data_ptr(), Vd.shape[1], vsp, vtp, int(self.v_relu),
+                                              dd.row_w.data_ptr(), B, npoint, self.D, out.data_ptr(), self.D,
+                                              _stream()), "patch_rows")
+            _tap("block_out", out)
+            return out
         if FUSE_SCORE_POOL and K in (8, 16, 32) and (npoint * K) % 32 == 0 and self.D % 4 == 0:
             # last score conv + mask + softmax over K + weighted sum in ONE kernel: scores stay in the
             # MFMA accumulators
@@ -724,17 +829,17 @@ class FusedAttention:
                                                      int(self.v_relu), cptr, K, out.data_ptr(), self.D, _stream())
                 if rc != _lib.PDR_EUNSUPPORTED:
                     _lib.check(rc, "fused_layer_pool_f16x3")
-                    return out
+                    return patch()
             _lib.check(lib.pdr_fused_layer_pool(ctypes.byref(li), P, self.w2.Cin, self.w2.Wt.data_ptr(), self.w2.ldw,
                                                 self.w2.bias.data_ptr(), self.D, V.data_ptr(), V.shape[1], vsp, vtp,
                                                 int(self.v_relu), cptr, K, out.data_ptr(), self.D, _stream()),
                        "fused_layer_pool")
-            return out
+            return patch()
         scores, _, _ = run_layer(score_in, self.w2)
         _lib.check(lib.pdr_attention_pool(scores.data_ptr(), scores.shape[1], V.data_ptr(), V.shape[1], vsp, vtp,
                                           int(self.v_relu), cptr, B, npoint, K, self.D, out.data_ptr(), _stream()),
                    "attention_pool")
-        return out
+        return patch()
 
 
 class _RawConv:
@@ -822,7 +927,7 @@ class SplitFirstConv:
         return V2
 
     def __call__(self, src_feats_cl, src_xyz, query_xyz, idx32, counts, K, relu_col0, s1=None, s2=None,
-                 virtual=False, res=None, U=None, V2=None, fold=None):
+                 virtual=False, res=None, U=None, V2=None, fold=None, dd=None):
         """-> (Y1, partial, tiles_per_batch, folded).  Y1 = (B*m*K, ld) tensor, or with virtual=True a FirstOut that
         consumers read as a gathered source (only the GroupNorm moments are computed here).  fold: FoldReq of the
         GroupNorm behind this conv; folded = a thunk launching that fold -> (scale, shift), None without request."""
@@ -841,19 +946,34 @@ class SplitFirstConv:
         tpb = (rpb + 127) // 128
         virtual = virtual and (s1 is None) == (s2 is None) and (K & (K - 1)) == 0 and 128 % K == 0 and \
             not (s1 is not None and has_v0)
+        # deduplicated evaluation (dd, a Dedup plan): the virtual ball form with a gathered (or no) residual only
+        if dd is not None and not (virtual and s1 is None and (res is None or res[1] <= GATHER_RES)):
+            dd = None
         Y = None if virtual else torch.empty((B * rpb, ld), dtype=torch.float32, device=U.device)
-        partial = torch.empty((B * tpb, self.Cout, 2), dtype=torch.float32, device=U.device)
+        ptpb = dd.ptpb if dd is not None else tpb
+        partial = torch.empty((B * ptpb, self.Cout, 2), dtype=torch.float32, device=U.device)
         cptr = counts.data_ptr() if has_v0 else None
 
         def gather_add(y, ldy, ycol0, ycols):
+            args = (U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
+                    s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
+                    s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
+                    B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols)
+            if dd is None:
+                _lib.check(lib.pdr_gather_add(*args, _stream()), "gather_add")
+                return
+            _lib.check(lib.pdr_gather_add_tiles(*args, dd.tile_valid.data_ptr(), ptpb, _stream()), "gather_add_tiles")
+            # the first conv of every query's FIRST neighbour, materialised (B m rows): the per-query chain's input
+            Yd = torch.empty((B * m, ld), dtype=torch.float32, device=U.device)
             _lib.check(lib.pdr_gather_add(
-                U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
-                s1.data_ptr() if s1 is not None else None, self.r1.data_ptr() if s1 is not None else None,
-                s2.data_ptr() if s2 is not None else None, self.r2.data_ptr() if s2 is not None else None,
-                B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols, _stream()), "gather_add")
+                U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, dd.idx0.data_ptr(), cptr,
+                None, None, None, None, B, m, 1, self.Cout, Yd.data_ptr(), ld, None, relu_col0, 0, -1, _stream()),
+                "gather_add")
+            dd.moments(Yd, self.Cout, relu_col0, partial)
+            dd.Yd = Yd
 
         # (a thunk: the fold is launched by whoever consumes it, i.e. on the stream that runs the rest of the MLP)
-        folded = (lambda: fold.launch(partial, tpb, B)) if fold is not None else None
+        folded = (lambda: fold.launch(partial, ptpb, B)) if fold is not None else None
 
         if not virtual:
             gather_add(Y.data_ptr(), ld, 0, -1)
@@ -885,7 +1005,9 @@ class SplitFirstConv:
                          nsrc=n, zrow=B * n, Yres=Yres, res_col0=res[0] if res else 0,
                          res_cols=res[1] if res else 0, s1=s1, s2=s2, r1=self.r1 if s1 is not None else None,
                          r2=self.r2 if s1 is not None else None, materialise=materialise)
-        return first, partial, tpb, folded
+        if dd is not None:
+            first.dd, first.deg = dd, dd.Yd
+        return first, partial, ptpb, folded
 
 
 def group_build(feats_cl, xyz, new_xyz, idx, counts, patch_empty, with_abs, with_centre):
@@ -954,6 +1076,13 @@ class FusedGroupedBlock:
         self.mlp = FusedMlp(mlp, bank, extra_convs=[self.att.key_conv])
         self.split = None   # built lazily (needs the source feature width)
         self.static_U = None
+        self.dedup = False  # evaluate one-point neighbourhoods once (set for the x_t branch, see Dedup)
+
+    def _plan(self, idx, counts, B, m, K):
+        if not (DEDUP and self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
+                K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32):
+            return None
+        return Dedup(idx, counts, B, m, K)
 
     def _make_split(self, Cs):
         if self.split is None:
@@ -995,7 +1124,8 @@ class FusedGroupedBlock:
             Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                     self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                     res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
-                                    U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K))
+                                    U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K),
+                                    dd=self._plan(idx, counts, B, m, K))
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank, folded=folded)
         else:
             dense_feats = src_feats_cl.dense() if isinstance(src_feats_cl, Cat) else src_feats_cl
@@ -1023,7 +1153,8 @@ class FusedGroupedBlock:
         Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                 self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                 res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
-                                U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K))
+                                U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K),
+                                dd=self._plan(idx, counts, B, m, K))
 
         mark("  blk:first_conv_stats_done", True)
 
@@ -1199,6 +1330,10 @@ class FusedCloudConditionNet:
             blk.npoint = sa.npoint
             self.sa.append(blk)
         self.fp = [FusedKnnFP(fp, b) for fp in net.FP_modules]
+        # the blocks of the x_t branch see noise-like clouds for most of a reverse process: their one-point
+        # neighbourhoods are evaluated once (Dedup); the condition branch (a surface, once per batch) runs whole
+        for blk in self.enc_map + self.dec_map + self.sa:
+            blk.dedup = True
         # condition branch (evaluated once per batch): same block types, no embeddings (include_t / condition False)
         self.cond_sa = []
         for sa in net.SA_modules_condition:
