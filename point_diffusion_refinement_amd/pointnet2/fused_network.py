@@ -94,13 +94,6 @@ def _stream():
 # mark(name) launches pdr_mark_time on the CURRENT stream; capturable, so the stamps of an untraced graph replay
 # can be read back afterwards.  None = no launches (the default).
 MARKS = None
-TAPS = None          # lab: list collecting (name, tensor clone) when set
-
-
-def _tap(name, t):
-    if TAPS is not None and t is not None:
-        TAPS.append((name, t.detach().clone()))
-
 
 
 def mark(name, detail=False):
@@ -573,8 +566,6 @@ class Norm:
                                    scale.data_ptr(), shift.data_ptr(), _stream()), "gn_fold")
         if LAB_SKIP_FOLD:
             self._lab_fold[(B, C, n)] = (scale, shift)
-        _tap("fold_scale", scale)
-        _tap("fold_shift", shift)
         return scale, shift
 
 
@@ -808,7 +799,6 @@ class FusedAttention:
                 _lib.check(lib.pdr_patch_rows(Vd.data_ptr(), Vd.shape[1], vsp, vtp, int(self.v_relu),
                                               dd.row_w.data_ptr(), B, npoint, self.D, out.data_ptr(), self.D,
                                               _stream()), "patch_rows")
-            _tap("block_out", out)
             return out
         if FUSE_SCORE_POOL and K in (8, 16, 32) and (npoint * K) % 32 == 0 and self.D % 4 == 0:
             # last score conv + mask + softmax over K + weighted sum in ONE kernel: scores stay in the
@@ -1079,10 +1069,22 @@ class FusedGroupedBlock:
         self.dedup = False  # evaluate one-point neighbourhoods once (set for the x_t branch, see Dedup)
 
     def _plan(self, idx, counts, B, m, K):
+        """The Dedup plan of this block's neighbourhoods, or None when the block runs whole.  A plan made earlier for
+        the same index tensor (plan_ahead: on the geometry stream, shared by the encoder / decoder feature-transfer
+        blocks of a level) is reused."""
         if not (DEDUP and self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
                 K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32):
             return None
-        return Dedup(idx, counts, B, m, K)
+        dd = getattr(idx, "_plan", None)
+        if dd is None:
+            dd = idx._plan = Dedup(idx, counts, B, m, K)
+        return dd
+
+    def plan_ahead(self, neigh):
+        """Launch the plan on the CURRENT stream (the one that produced `neigh`), ahead of the block."""
+        idx, counts = neigh
+        self._plan(idx, counts, idx.shape[0], idx.shape[1], idx.shape[2])
+        return neigh
 
     def _make_split(self, Cs):
         if self.split is None:
@@ -1553,7 +1555,7 @@ class FusedCloudConditionNet:
         ev_first = None
         with torch.cuda.stream(side):
             mark("side:begin")
-            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].neighbours(l_uvw[0], xyz)
+            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].plan_ahead(self.enc_map[0].neighbours(l_uvw[0], xyz))
             if SIDE_TABLES and LEVEL_EVENTS and self.enc_map[0].split is not None:
                 tables[id(self.enc_map[0])] = self.enc_map[0].split.query_tables(xyz, has_v0=True)
             mark("side:first_ball_query_done")
@@ -1568,7 +1570,7 @@ class FusedCloudConditionNet:
                 sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
                 sels.append(sel)
                 l_xyz.append(gather_rows(l_xyz[i], sel))
-                sa_neigh.append(sa.neighbours(l_xyz[i], l_xyz[i + 1]))
+                sa_neigh.append(sa.plan_ahead(sa.neighbours(l_xyz[i], l_xyz[i + 1])))
                 if LEVEL_EVENTS:
                     xyz4(l_xyz[i + 1])          # padded coordinates of the new level: produced before its event
                     if SIDE_TABLES and sa.split is not None:
@@ -1579,7 +1581,7 @@ class FusedCloudConditionNet:
                     lv = i + 1
                     for blk in ([self.enc_map[lv]] if lv < nlev else []) + [self.dec_map[lv]]:
                         if fm_key(lv, blk) not in fm_neigh:
-                            fm_neigh[fm_key(lv, blk)] = blk.neighbours(l_uvw[lv], l_xyz[lv])
+                            fm_neigh[fm_key(lv, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[lv], l_xyz[lv]))
                         if SIDE_TABLES and blk.split is not None:
                             tables[id(blk)] = blk.split.query_tables(l_xyz[lv], has_v0=True)
                     ev_fm[lv] = torch.cuda.Event()
@@ -1587,7 +1589,7 @@ class FusedCloudConditionNet:
             for i in range(nlev + 1):
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
-                        fm_neigh[fm_key(i, blk)] = blk.neighbours(l_uvw[i], l_xyz[i])
+                        fm_neigh[fm_key(i, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[i], l_xyz[i]))
             mark("side:encoder_geometry_done")
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)

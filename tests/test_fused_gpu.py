@@ -311,6 +311,7 @@ _VARIANTS = [
     ("grouped_first_conv", {"PDR_FUSED_OPTS": "USE_SPLIT_FIRST=0"}, False),
     ("layerwise_condition_branch", {"PDR_FUSED_OPTS": "FUSE_CONDITION_BRANCH=0"}, False),
     ("torch_global_pointnet", {"PDR_FUSED_OPTS": "FUSE_GLOBAL_PNET=0"}, False),
+    ("whole_neighbourhoods", {"PDR_FUSED_OPTS": "DEDUP=0"}, False),
 ]
 
 
@@ -1037,3 +1038,175 @@ def test_gather_add_matches_torch(cuda, case):
         wm = torch.stack([blk.sum(1), (blk * blk).sum(1)], -1)
         got = partial.view(B, tpb, Cout, 2)[:, t].double()
         assert ((got - wm).abs() <= 1e-4 * (wm.abs() + 1)).all(), (case, t)
+
+
+def _ball_like_neighbourhoods(B, m, K, n_src, dev, seed, frac_many=0.1, small=3):
+    """idx / counts as ball_query leaves them: slots >= count repeat the first hit; counts 0 .. small-1 and a few 7."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    counts = torch.randint(0, small, (B, m), device=dev, dtype=torch.int32, generator=g)
+    counts[torch.rand(B, m, device=dev, generator=g) < frac_many] = 7
+    first = torch.randint(0, n_src, (B, m, 1), device=dev, dtype=torch.int32, generator=g)
+    rest = torch.randint(0, n_src, (B, m, K), device=dev, dtype=torch.int32, generator=g)
+    slot = torch.arange(K, device=dev)[None, None, :]
+    idx = torch.where(slot < counts[:, :, None], rest, first.expand(B, m, K)).contiguous()
+    idx[:, :, 0] = first[:, :, 0]
+    return idx, counts
+
+
+@pytest.mark.parametrize("K", [32, 8])
+def test_dedup_plan_tiles_and_weighted_moments_equal_the_whole_first_conv(cuda, K):
+    """pdr_dedup_plan (valid tiles = any query with more than one neighbour, ascending list, first neighbours, weights)
+    and the three launches that replace a whole pdr_gather_add -- pdr_gather_add_tiles over the valid tiles, the
+    per-query pdr_gather_add (K = 1), pdr_weighted_moments -- give the same per-cloud GroupNorm moments; valid tiles'
+    partial rows are bit-equal, skipped tiles' rows zero."""
+    lib, dev = _lib.load(), cuda
+    B, m, Cout, n_src, relu_col0 = 3, 1024, 96, 700, 64
+    ld, qpt = Cout, 128 // K
+    g = torch.Generator(device=dev).manual_seed(K)
+    U = torch.randn(B * n_src + 1, ld, device=dev, generator=g)
+    V2 = torch.randn(B * m, 2 * ld, device=dev, generator=g)
+    # (a tile of 128 / K queries is skipped when ALL of them have <= 1 neighbour)
+    idx, counts = _ball_like_neighbourhoods(B, m, K, n_src, dev, 10 + K, *((0.1, 3) if K == 32 else (0.05, 2)))
+    st = torch.cuda.current_stream().cuda_stream
+    tpb, tpbd = m * K // 128, (m + 127) // 128
+    ptpb = tpb + tpbd
+    full = torch.empty(B * tpb, Cout, 2, device=dev)
+    tabs = (U.data_ptr(), ld, n_src, V2.data_ptr(), V2.data_ptr() + 4 * ld, 2 * ld)
+    _lib.check(lib.pdr_gather_add(*tabs, idx.data_ptr(), counts.data_ptr(), None, None, None, None, B, m * K, K, Cout,
+                                  None, ld, full.data_ptr(), relu_col0, 0, -1, st), "gather_add")
+    idx0 = torch.empty(B, m, dtype=torch.int32, device=dev)
+    row_w = torch.empty(B * m, device=dev)
+    tv = torch.empty(B * tpb, dtype=torch.uint8, device=dev)
+    tl = torch.full((B * tpb,), -1, dtype=torch.int32, device=dev)
+    nt = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.pdr_dedup_plan(idx.data_ptr(), counts.data_ptr(), B, m, K, idx0.data_ptr(), row_w.data_ptr(),
+                                  tv.data_ptr(), tl.data_ptr(), nt.data_ptr(), st), "dedup_plan")
+    want_valid = (counts.view(-1, qpt) > 1).any(1)
+    assert 0 < int(nt) < B * tpb and int(nt) == int(want_valid.sum())
+    assert torch.equal(tl[:int(nt)].long(), want_valid.nonzero()[:, 0]) and torch.equal(tv.bool(), want_valid)
+    assert torch.equal(idx0, idx[:, :, 0])
+    assert torch.equal(row_w.view(-1, qpt), (~want_valid)[:, None].float().expand(-1, qpt) * K)
+    part = torch.full((B * ptpb, Cout, 2), float("nan"), device=dev)
+    _lib.check(lib.pdr_gather_add_tiles(*tabs, idx.data_ptr(), counts.data_ptr(), None, None, None, None, B, m * K, K,
+                                        Cout, None, ld, part.data_ptr(), relu_col0, 0, -1, tv.data_ptr(), ptpb, st),
+               "gather_add_tiles")
+    Yd = torch.empty(B * m, ld, device=dev)
+    _lib.check(lib.pdr_gather_add(*tabs, idx0.data_ptr(), counts.data_ptr(), None, None, None, None, B, m, 1, Cout,
+                                  Yd.data_ptr(), ld, None, relu_col0, 0, -1, st), "gather_add")
+    _lib.check(lib.pdr_weighted_moments(Yd.data_ptr(), ld, B, m, Cout, relu_col0, row_w.data_ptr(), part.data_ptr(),
+                                        ptpb, tpb, tv.data_ptr(), st), "weighted_moments")
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(part).any())
+    pv = part.view(B, ptpb, Cout, 2)[:, :tpb].reshape(B * tpb, Cout, 2)
+    assert torch.equal(pv[want_valid], full[want_valid]) and bool((pv[~want_valid] == 0).all())
+    a, b = full.view(B, tpb, Cout, 2).double().sum(1), part.view(B, ptpb, Cout, 2).double().sum(1)
+    assert float(((a - b).abs() / (a.abs() + 1)).max()) < 1e-4
+    # pooled rows of the skipped tiles' queries: the activated value row; the others untouched
+    D = 32
+    V = torch.randn(B * m, D, device=dev, generator=g)
+    vs, vt = torch.rand(B, D, device=dev, generator=g) + 0.5, torch.randn(B, D, device=dev, generator=g)
+    out = torch.full((B * m, D), 7.0, device=dev)
+    _lib.check(lib.pdr_patch_rows(V.data_ptr(), D, vs.data_ptr(), vt.data_ptr(), 1, row_w.data_ptr(), B, m, D,
+                                  out.data_ptr(), D, st), "patch_rows")
+    want = torch.where((row_w > 0)[:, None], torch.relu(torch.addcmul(vt.repeat_interleave(m, 0), V,
+                                                                     vs.repeat_interleave(m, 0))),
+                       torch.full_like(out, 7.0))
+    assert ((out - want).abs() <= 1e-6 * (want.abs() + 1)).all()
+
+
+@pytest.mark.parametrize("shape", [(4096, 32, 32, 0), (4096, 64, 128, 0), (2048, 128, 128, 32), (4096, 41, 32, 32)])
+def test_layer_tile_subset_matches_the_whole_layer_on_its_tiles(cuda, shape):
+    """pdr_layer_in_t.tile_list: the listed 128-row tiles get bit-identical rows of Y and of the moments (written to
+    row b * partial_tpb + t), every other row of both buffers is left untouched; plain and ball-gathered sources."""
+    rpb, Cin, Cout, gath = shape
+    lib, dev = _lib.load(), cuda
+    B = 5
+    g = torch.Generator(device=dev).manual_seed(rpb + Cin)
+    P, ldx, ldw = B * rpb, (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    Wt = torch.randn(Cin, ldw, device=dev, generator=g) * 0.1
+    bias = torch.randn(Cout, device=dev, generator=g)
+    scale, shift = torch.rand(B, Cin, device=dev, generator=g) + 0.5, torch.randn(B, Cin, device=dev, generator=g)
+    li = _lib.LayerIn()
+    li.n_seg = 1
+    keep = []
+    if gath:
+        K, n_src = gath, 300
+        U = torch.randn(B * n_src + 1, ldx, device=dev, generator=g)
+        U[-1].zero_()
+        V2 = torch.randn(P // K, 2 * ldx, device=dev, generator=g)
+        idx = torch.randint(0, n_src, (P,), device=dev, dtype=torch.int32, generator=g)
+        cnt = torch.randint(0, 3, (P // K,), device=dev, dtype=torch.int32, generator=g)
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = U.data_ptr(), Cin, ldx, 1
+        li.seg[0].gV, li.seg[0].gV0 = V2.data_ptr(), V2.data_ptr() + 4 * ldx
+        li.seg[0].g_ldv, li.seg[0].g_nsrc, li.seg[0].g_zrow = 2 * ldx, n_src, B * n_src
+        li.gidx, li.gcnt, li.gK = idx.data_ptr(), cnt.data_ptr(), K
+        keep += [U, V2, idx, cnt]
+    else:
+        X = torch.randn(P, ldx, device=dev, generator=g)
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, ldx, 1
+        keep.append(X)
+    li.scale, li.shift, li.pre_relu, li.post_relu, li.rows_per_batch = scale.data_ptr(), shift.data_ptr(), 0, 1, rpb
+    assert lib.pdr_fused_layer_tile_rows(rpb, Cout) == 128
+    tpb = rpb // 128
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(y, part):
+        _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout,
+                                       y.data_ptr(), ldw, part.data_ptr(), Cout // 2, st), "fused_layer")
+        torch.cuda.synchronize()
+    Y0, p0 = torch.empty(P, ldw, device=dev), torch.empty(B * tpb, Cout, 2, device=dev)
+    run(Y0, p0)
+    ntile = B * tpb
+    pick = (torch.rand(ntile, device=dev, generator=g) < 0.3)
+    pick[0], pick[-1] = True, False
+    tl = torch.full((ntile,), -1, dtype=torch.int32, device=dev)
+    sel = pick.nonzero()[:, 0].int()
+    tl[:len(sel)] = sel
+    nt = torch.tensor([len(sel)], dtype=torch.int32, device=dev)
+    ptpb = tpb + 3
+    li.tile_list, li.n_tiles, li.partial_tpb = tl.data_ptr(), nt.data_ptr(), ptpb
+    Y1, p1 = torch.full((P, ldw), -5.0, device=dev), torch.full((B * ptpb, Cout, 2), -5.0, device=dev)
+    run(Y1, p1)
+    rows = pick.repeat_interleave(128)
+    assert torch.equal(Y1[rows][:, :Cout], Y0[rows][:, :Cout]) and bool((Y1[~rows] == -5.0).all())
+    pv = p1.view(B, ptpb, Cout, 2)
+    assert torch.equal(pv[:, :tpb].reshape(ntile, Cout, 2)[pick], p0[pick])
+    assert bool((pv[:, :tpb].reshape(ntile, Cout, 2)[~pick] == -5.0).all()) and bool((pv[:, tpb:] == -5.0).all())
+    # an empty list is a launch that does nothing
+    nt.zero_()
+    Y2 = torch.full((P, ldw), -5.0, device=dev)
+    run(Y2, p1)
+    assert bool((Y2 == -5.0).all())
+
+
+@pytest.mark.parametrize("cloud", ["noise", "surface"])
+def test_one_point_neighbourhoods_evaluated_once_match_the_whole_evaluation(cuda, cloud, monkeypatch):
+    """DEDUP on vs off on the DDPM configuration: eps of a cached step agrees to fp32 summation order on a noise-like
+    x_t (most tiles skipped) and on a surface-like one (few skipped), and both agree with the layer-by-layer network."""
+    from tests import parity
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
+    fused = FN.FusedCloudConditionNet(net)
+    x, cond, label = synthetic_batch(2, seed=5, device=cuda)
+    if cloud == "surface":
+        x = 0.5 * x / x.norm(dim=2, keepdim=True)            # points on a sphere: full balls at the coarse levels
+        cond = torch.cat([x[:, :1536] * 1.0, x[:, :1536] * torch.tensor([1.0, 1.0, -1.0], device=cuda)], 1)
+        cond = torch.cat([cond, torch.ones(2, 3072, 1, device=cuda)], 2).contiguous()
+    ts = torch.tensor([300.0, 40.0], device=cuda)
+    plans = []
+    init = FN.Dedup.__init__
+
+    def rec(self, *a, **k):
+        init(self, *a, **k)
+        plans.append(self)
+    monkeypatch.setattr(FN.Dedup, "__init__", rec)
+    outs = {}
+    for on in (False, True):
+        monkeypatch.setattr(FN, "DEDUP", on)
+        outs[on], ref = _cached_eps(net, fused, x, cond, ts, label)
+    torch.cuda.synchronize()
+    walked = sum(int(p.n_tiles) for p in plans) / float(sum(p.B * p.tpb for p in plans))
+    assert plans and (walked < 0.6 if cloud == "noise" else walked > 0.5), walked
+    parity.check("dedup:%s:on_vs_off" % cloud, "hip", outs[True], outs[False], 2e-5)
+    err = ((outs[True] - ref).abs() / (ref.abs() + 1.0))
+    assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
