@@ -409,9 +409,14 @@ def main():
                    "global_batch": world * B, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph replay", "noise": "device Philox",
                    **({"single_stream": True} if args.single_stream else {}),
-                   "execution": "layer-by-layer torch + native ops" if args.unfused else "fused channel-last HIP"},
+                   "execution": "layer-by-layer torch + native ops" if args.unfused else "fused channel-last HIP",
+                   **({} if args.unfused else
+                      {"neighbourhoods": "K identical rows of a <= 1-point ball evaluated once (results unchanged; "
+                                         "see one_point_neighbourhoods for the share walked and the whole evaluation)"})},
         "completed_points_per_s_per_gpu": round(value / world * N_POINTS / T_STEPS, 2),
         "first_uncached_step_ms": round(first_step_s * 1e3, 2),
+        # (the REFERENCE's GEMM work per cloud-step / time: an equivalent rate -- the executed flops are fewer: split first
+        # conv, one-point neighbourhoods evaluated once)
         "gemm_tflops": round(value * GEMM_GFLOP_PER_CLOUD_STEP / 1e3, 2),
         "ranks_seen": int(sum(1 for c in counts if c > 0)), "records_gathered": int(allrec.shape[0]),
         "metric_gather": {"collective": "all_gather of (n,5) f32 records [cd_t, cd_p, f1, emd, label]",
@@ -428,6 +433,48 @@ def main():
             out["roofline"] = dominant_kernel_roofline(sampler)
         except Exception as e:  # never lose the headline number to an instrumentation problem
             out["roofline"] = {"error": repr(e)}
+    if solo and not args.no_extras and not args.unfused:
+        # The headline evaluates neighbourhoods that are K copies of one row ONCE (fused_network.DEDUP):
+        # x_T and the x_t of this benchmark are noise, as they are for most of a reverse process, so most balls hold at
+        # most one point.  Reported next to it: how much of the per-neighbour tile work the headline walked, and the
+        # same step with every neighbourhood evaluated in full (the cost on ANY input, e.g. a finished surface).
+        try:
+            from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
+            plans, init = [], FN.Dedup.__init__
+
+            def rec(self, *a, **k):
+                init(self, *a, **k)
+                plans.append(self)
+            FN.Dedup.__init__ = rec
+            try:
+                s3, _ = build_sampler(device, False, precision=args.precision)
+                s3.begin((B, N_POINTS, 3), cond, label, x_T=x_T)
+                plans.clear()
+                s3.advance(1)
+                torch.cuda.synchronize(device)
+                walked = sum(int(p.n_tiles) for p in plans) / max(1.0, float(sum(p.B * p.tpb for p in plans)))
+            finally:
+                FN.Dedup.__init__ = init
+            del s3
+            FN.DEDUP = False
+            try:
+                s4, _ = build_sampler(device, not args.no_graph, precision=args.precision)
+                el4, _ = timed_steps(s4, args.steps, args.warmup)
+            finally:
+                FN.DEDUP = True
+            del s4
+            out["one_point_neighbourhoods"] = {
+                "evaluated_once": True, "tiles_walked_frac": round(walked, 3),
+                "whole_evaluation": {"value": round(B * args.steps / el4, 2), "unit": "cloud-steps/s",
+                                     "ms_per_step": round(el4 / args.steps * 1e3, 4)},
+                "note": "ball_query pads a neighbourhood with its first hit: a query with <= 1 point in its ball "
+                        "contributes K identical rows to every per-neighbour tensor of its block.  128-row tiles made of "
+                        "such queries only are skipped by the per-neighbour launches; a per-query chain supplies their "
+                        "GroupNorm moments (x K) and pooled rows -- same results (tests/test_fused_gpu.py::"
+                        "test_one_point_neighbourhoods_*, the reference goldens).  tiles_walked_frac: share of the "
+                        "deduplicated blocks' tiles this input needed; whole_evaluation: the step with nothing skipped"}
+        except Exception as e:
+            out["one_point_neighbourhoods"] = {"error": repr(e)}
     if solo and not args.no_extras and not args.unfused and args.precision == "f32":
         try:
             s2, _ = build_sampler(device, not args.no_graph, precision="split_f16")

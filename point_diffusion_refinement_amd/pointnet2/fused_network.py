@@ -1068,12 +1068,37 @@ class FusedGroupedBlock:
         self.static_U = None
         self.dedup = False  # evaluate one-point neighbourhoods once (set for the x_t branch, see Dedup)
 
+    _WS_ON = []
+
+    @staticmethod
+    def _ws_kernels_on():
+        """Tile subsets are walked by the wave-specialised layer kernels only (PDR_FUSED_WS=0 turns them off)."""
+        if not FusedGroupedBlock._WS_ON:
+            li = _lib.LayerIn()
+            li.n_seg = 1
+            li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = 0x1000, 64, 64, 1     # (never dereferenced)
+            li.rows_per_batch = 8192
+            plan = (ctypes.c_int * 8)()
+            rc = _lib.load().pdr_fused_layer_plan(ctypes.byref(li), 8192, 64, 0x1000, 64, 64, 0x1000, 64, plan)
+            FusedGroupedBlock._WS_ON.append(rc == 0 and plan[0] == 1)
+        return FusedGroupedBlock._WS_ON[0]
+
+    def _tiles_128(self, rpb):
+        """Every per-neighbour layer of this block runs on 128-row tiles (the granularity of a plan)."""
+        key = ("_t128", rpb)
+        if key not in self.__dict__:
+            tr = _lib.load().pdr_fused_layer_tile_rows
+            couts = [c.Cout for c in self.mlp.rest] + [self.att.v.Cout, self.att.w1.Cout, self.att.w2.Cout]
+            self.__dict__[key] = all(tr(rpb, c) == 128 for c in couts)
+        return self.__dict__[key]
+
     def _plan(self, idx, counts, B, m, K):
         """The Dedup plan of this block's neighbourhoods, or None when the block runs whole.  A plan made earlier for
         the same index tensor (plan_ahead: on the geometry stream, shared by the encoder / decoder feature-transfer
         blocks of a level) is reused."""
         if not (DEDUP and self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
-                K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32):
+                K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32 and
+                self._ws_kernels_on() and self._tiles_128(m * K)):
             return None
         dd = getattr(idx, "_plan", None)
         if dd is None:

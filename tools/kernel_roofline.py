@@ -163,6 +163,11 @@ def step_kernel_table(sampler, reps=3):
     saved_par = getattr(net, "two_streams", None)
     if saved_par is not None:
         net.two_streams = False
+    # every launch over ALL its tiles: the algorithmic flops / bytes of _work() are those of whole launches, and a
+    # kernel's roofline is a property of the kernel, not of how many of its tiles an input happens to need (the
+    # headline step evaluates one-point neighbourhoods once: fused_network.DEDUP, a device-side tile subset)
+    from point_diffusion_refinement_amd.pointnet2 import fused_network as _FN
+    saved_dedup, _FN.DEDUP = _FN.DEDUP, False
     records = []
     installed = []
     for name in _TIMED:
@@ -188,6 +193,7 @@ def step_kernel_table(sampler, reps=3):
                 sampler._step()           # eager: the graph is not involved
         torch.cuda.synchronize()
     finally:
+        _FN.DEDUP = saved_dedup
         if saved_par is not None:
             net.two_streams = saved_par
         for name, fn in installed:
@@ -235,7 +241,9 @@ def dominant_kernel_roofline(sampler, reps=3):
         "share_of_step_kernel_time": round(ms / total, 4),
         "note": "dominant = largest HIP-event time among the C-ABI launches of %d eager steps with the blocks' halves "
                 "serialised on one stream (a kernel alone on the chip; agrees with profiles/*_bench_kernel_stats_serial"
-                ".csv); events include ~3 us of eager launch latency per call" % reps,
+                ".csv); events include ~3 us of eager launch latency per call; measured with every neighbourhood "
+                "evaluated (whole launches: the shares are those of the whole evaluation, not of the headline step, "
+                "whose per-neighbour launches walk a tile subset)" % reps,
         "next": [{"kernel": s, "share": round(v[1] / total, 4), "avg_launch_us": round(v[1] / v[0] * 1e3, 2),
                   **_roof(v[2], v[3], v[1], s, v[4])} for s, v in ranked[1:6]],
     })
