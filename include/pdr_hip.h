@@ -378,6 +378,11 @@ int pdr_gather_add(const float *U, int ldu, int n_src, const float *V, const flo
  * valid row-tile numbers, ascending) and n_tiles (1).  K in {8,16,32}, m*K a multiple of 128. */
 int pdr_dedup_plan(const int *idx, const int *counts, int B, int m, int K, int *idx0, float *row_w,
                    unsigned char *tile_valid, int *tile_list, int *n_tiles, pdr_stream_t stream);
+/* Stable partition of every cloud's queries, those with more than one neighbour first: perm[b][j] = original index
+ * of the query at sorted position j, inv = the inverse.  A block evaluated on its queries in that order (its per-query
+ * inputs through pdr_gather_rows with perm, its output through pdr_gather_rows with inv) has its one-point
+ * neighbourhoods in whole tiles. */
+int pdr_dedup_sort(const int *counts, int B, int m, int *perm, int *inv, pdr_stream_t stream);
 /* pdr_gather_add over the tiles with tile_valid[tile] != 0 only (the others are neither read nor written); tile t
  * of batch element b writes row b * partial_tpb + t of `partial`. */
 int pdr_gather_add_tiles(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "pdr_gather_add_tiles": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I,
                                   _P, _I, _P]),
     "pdr_dedup_plan": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "pdr_dedup_sort": (_I, [_P, _I, _I, _P, _P, _P]),
     "pdr_weighted_moments": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "pdr_patch_rows": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P]),
 }

@@ -676,6 +676,55 @@ __global__ __launch_bounds__(1024) void dedup_compact_kernel(const unsigned char
   if (tid == 0) *n_tiles = base_s;
 }
 
+// Stable partition of a cloud's queries: those with more than one neighbour first (in their original order), the
+// one-point ones behind them.  perm[b][j] = original index of the query at sorted position j, inv = its inverse.
+// One workgroup per cloud; chunks of 1024 queries, two passes (real neighbourhoods, then the rest).
+__global__ __launch_bounds__(1024) void dedup_sort_kernel(const int* __restrict__ counts, int m,
+                                                         int* __restrict__ perm, int* __restrict__ inv) {
+  __shared__ int wtot[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int* cb = counts + static_cast<long>(blockIdx.x) * m;
+  int* pb = perm + static_cast<long>(blockIdx.x) * m;
+  int* ib = inv + static_cast<long>(blockIdx.x) * m;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+      const int i = i0 + tid;
+      const bool take = i < m && ((cb[i] > 1) == (pass == 0));
+      const unsigned long long bal = __ballot(take);
+      const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wtot[wave] = __builtin_popcountll(bal);
+      __syncthreads();
+      int woff = 0, tot = 0;
+      for (int w = 0; w < 16; ++w) {
+        woff += w < wave ? wtot[w] : 0;
+        tot += wtot[w];
+      }
+      const int base = base_s;
+      if (take) {
+        const int j = base + woff + before;
+        pb[j] = i;
+        ib[i] = j;
+      }
+      __syncthreads();
+      if (tid == 0) base_s = base + tot;
+      __syncthreads();
+    }
+  }
+}
+
+// counts (B, m) -> perm, inv (B, m) int32: see dedup_sort_kernel.  A block evaluated on its queries in `perm` order
+// (pdr_gather_rows of its per-query inputs) has its one-point neighbourhoods in whole tiles; pdr_gather_rows with
+// `inv` puts its output back.
+extern "C" int pdr_dedup_sort(const int* counts, int B, int m, int* perm, int* inv, pdr_stream_t stream) {
+  if (!counts || !perm || !inv || B < 0 || m <= 0) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  hipLaunchKernelGGL(dedup_sort_kernel, dim3(B), dim3(1024), 0, pdr::as_stream(stream), counts, m, perm, inv);
+  return pdr::check_launch();
+}
+
 // idx (B, m, K) int32 / counts (B, m) of a ball query ->
 //   idx0 (B, m): the first neighbour of every query;  row_w (B, m) float: K for the queries of skipped tiles, else 0;
 //   tile_valid (B * m K / 128) bytes, tile_list (same length, the valid tile numbers in ascending order), n_tiles (1).

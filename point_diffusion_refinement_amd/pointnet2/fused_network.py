@@ -81,9 +81,18 @@ LAB_SKIP_FOLD = False
 # the rule on x_t for most of a reverse process) are evaluated ONCE: the per-neighbour launches of a grouped block walk
 # only the 128-row tiles that contain a real neighbourhood (pdr_dedup_plan), a per-QUERY chain of the same layers
 # supplies the moments (x K) and the pooled rows of the others.  DESIGN.md section 4.7.  Blocks with fewer queries per
-# cloud than DEDUP_MIN_QUERIES run whole (their launches are latency-bound already).
+# cloud than DEDUP_MIN_QUERIES run whole (same box: 256 -> 6.98 ms, 64 -> 6.84 / 6.88, 512 -> 7.35 / 7.37).
 DEDUP = True
-DEDUP_MIN_QUERIES = 256
+DEDUP_MIN_QUERIES = 64
+# ... on the block's queries SORTED per cloud, real neighbourhoods first (pdr_dedup_sort): a tile is walked when ANY of
+# its 4 queries has a real neighbourhood, so unsorted 14 % such queries keep 45 % of the tiles; sorted, 14 %.  The
+# block's per-query inputs (index rows, counts, coordinates, query features) are gathered in that order, its output
+# is gathered back.
+DEDUP_SORT = True
+# (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
+# stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
+# (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
+# 5-us launches it hides.  Removed.)
 
 
 def _stream():
@@ -204,6 +213,23 @@ class Dedup:
         _lib.check(_lib.load().pdr_weighted_moments(Yd.data_ptr(), Yd.shape[1], self.B, self.m, C, relu_col0,
                                                     self.row_w.data_ptr(), partial.data_ptr(), self.ptpb, self.tpb,
                                                     self.tile_valid.data_ptr(), _stream()), "weighted_moments")
+
+
+class SortedQueries:
+    """A grouped block's queries in the order it evaluates them under DEDUP_SORT (pdr_dedup_sort of the ball counts):
+    permutation, inverse, and the ball query's outputs / the query coordinates gathered into that order."""
+
+    def __init__(self, idx, counts, new_xyz):
+        B, m, K = idx.shape
+        dev = idx.device
+        self.perm = torch.empty((B, m), dtype=torch.int32, device=dev)
+        self.inv = torch.empty((B, m), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().pdr_dedup_sort(counts.data_ptr(), B, m, self.perm.data_ptr(), self.inv.data_ptr(),
+                                              _stream()), "dedup_sort")
+        # (rows of 32-bit words moved as they are: the row gather does no arithmetic)
+        self.idx = gather_rows(idx.view(torch.float32), self.perm).view(torch.int32)
+        self.counts = gather_rows(counts.view(B, m, 1).view(torch.float32), self.perm).view(torch.int32).view(B, m)
+        self.xyz = gather_rows(new_xyz.contiguous(), self.perm)
 
 
 def act_from(Y, C, P, B, rpb, **kw):
@@ -1096,20 +1122,42 @@ class FusedGroupedBlock:
         """The Dedup plan of this block's neighbourhoods, or None when the block runs whole.  A plan made earlier for
         the same index tensor (plan_ahead: on the geometry stream, shared by the encoder / decoder feature-transfer
         blocks of a level) is reused."""
-        if not (DEDUP and self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
-                K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32 and
-                self._ws_kernels_on() and self._tiles_128(m * K)):
+        if not self._eligible(idx, m, K):
             return None
         dd = getattr(idx, "_plan", None)
         if dd is None:
             dd = idx._plan = Dedup(idx, counts, B, m, K)
         return dd
 
-    def plan_ahead(self, neigh):
-        """Launch the plan on the CURRENT stream (the one that produced `neigh`), ahead of the block."""
+    def _eligible(self, idx, m, K):
+        return (DEDUP and self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
+                K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32 and
+                self._ws_kernels_on() and self._tiles_128(m * K))
+
+    def _sorted(self, idx):
+        """The SortedQueries made for this index tensor, when this block evaluates its queries in that order."""
+        return getattr(idx, "_sorted", None) if (DEDUP and DEDUP_SORT and self.dedup) else None
+
+    def plan_ahead(self, neigh, new_xyz):
+        """On the CURRENT stream (the one that produced `neigh`), ahead of the block: the query order and the plan."""
         idx, counts = neigh
-        self._plan(idx, counts, idx.shape[0], idx.shape[1], idx.shape[2])
+        B, m, K = idx.shape
+        if self._eligible(idx, m, K):
+            if DEDUP_SORT and getattr(idx, "_sorted", None) is None:
+                idx._sorted = SortedQueries(idx, counts, new_xyz)
+            sq = self._sorted(idx)
+            if sq is not None:
+                self._plan(sq.idx, sq.counts, B, m, K)
+            else:
+                self._plan(idx, counts, B, m, K)
         return neigh
+
+    def side_tables(self, neigh, new_xyz, has_v0):
+        """Per-query tables of the first conv, for the query order the block will use (tagged with it)."""
+        sq = self._sorted(neigh[0])
+        V2 = self.split.query_tables(sq.xyz if sq is not None else new_xyz, has_v0=has_v0)
+        V2._sq = sq
+        return V2
 
     def _make_split(self, Cs):
         if self.split is None:
@@ -1146,6 +1194,11 @@ class FusedGroupedBlock:
         B, m, _ = new_xyz.shape
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
         K = self.nsample
+        sq = self._sorted(idx) if USE_SPLIT_FIRST else None
+        if sq is not None:                     # the block's queries in sorted order (finish() puts the output back)
+            idx, counts, new_xyz = sq.idx, sq.counts, sq.xyz
+        if getattr(V2, "_sq", None) is not sq:
+            V2 = None                          # tables of another query order: evaluated here instead
         if USE_SPLIT_FIRST:
             split = self._make_split(src_feats_cl.shape[2])
             Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
@@ -1159,14 +1212,17 @@ class FusedGroupedBlock:
             G, Cg = group_build(dense_feats, src_xyz, new_xyz, idx, counts, not subset, self.with_abs,
                                 self.with_centre)
             h, Y1, part1, tpb1 = self.mlp(plain(G, B, m * K, C=Cg), bank)
-        return dict(h=h, Y1=Y1, part1=part1, tpb1=tpb1, counts=counts, B=B, m=m, K=K,
+        return dict(h=h, Y1=Y1, part1=part1, tpb1=tpb1, counts=counts, B=B, m=m, K=K, sq=sq,
                     values=self.att.values(h, B, m, K))
 
     def finish(self, prep, query_feats_cl):
-        B, m, K = prep["B"], prep["m"], prep["K"]
+        B, m, K, sq = prep["B"], prep["m"], prep["K"], prep["sq"]
+        if sq is not None:
+            query_feats_cl = gather_rows(query_feats_cl, sq.perm)
         out = self.att(query_feats_cl.reshape(B * m, -1), prep["h"], prep["Y1"], prep["part1"], prep["tpb1"],
                        self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"])
-        return out.view(B, m, -1)
+        out = out.view(B, m, -1)
+        return gather_rows(out, sq.inv) if sq is not None else out
 
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
         B, m, _ = new_xyz.shape
@@ -1176,6 +1232,12 @@ class FusedGroupedBlock:
                                query_feats_cl)
         # deep level: first GEMM here, then [MLP + value conv] on the auxiliary stream beside [query / score convs]
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
+        sq = self._sorted(idx)
+        if sq is not None:                     # the block's queries in sorted order; its output is put back below
+            idx, counts, new_xyz = sq.idx, sq.counts, sq.xyz
+            query_feats_cl = gather_rows(query_feats_cl, sq.perm)
+        if getattr(V2, "_sq", None) is not sq:
+            V2 = None                          # tables of another query order: evaluated in the block instead
         split = self._make_split(src_feats_cl.shape[2])
         Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                 self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
@@ -1195,7 +1257,8 @@ class FusedGroupedBlock:
         out = self.att(query_feats_cl.reshape(B * m, -1), None, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K,
                        values=values)
         mark("  blk:pool_done", True)
-        return out.view(B, m, -1)
+        out = out.view(B, m, -1)
+        return gather_rows(out, sq.inv) if sq is not None else out
 
 
 class FusedKnnFP:
@@ -1580,9 +1643,9 @@ class FusedCloudConditionNet:
         ev_first = None
         with torch.cuda.stream(side):
             mark("side:begin")
-            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].plan_ahead(self.enc_map[0].neighbours(l_uvw[0], xyz))
+            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].plan_ahead(self.enc_map[0].neighbours(l_uvw[0], xyz), xyz)
             if SIDE_TABLES and LEVEL_EVENTS and self.enc_map[0].split is not None:
-                tables[id(self.enc_map[0])] = self.enc_map[0].split.query_tables(xyz, has_v0=True)
+                tables[id(self.enc_map[0])] = self.enc_map[0].side_tables(fm_neigh[fm_key(0, self.enc_map[0])], xyz, True)
             mark("side:first_ball_query_done")
             ev_first = torch.cuda.Event()
             ev_first.record(side)
@@ -1595,26 +1658,26 @@ class FusedCloudConditionNet:
                 sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
                 sels.append(sel)
                 l_xyz.append(gather_rows(l_xyz[i], sel))
-                sa_neigh.append(sa.plan_ahead(sa.neighbours(l_xyz[i], l_xyz[i + 1])))
+                sa_neigh.append(sa.plan_ahead(sa.neighbours(l_xyz[i], l_xyz[i + 1]), l_xyz[i + 1]))
                 if LEVEL_EVENTS:
                     xyz4(l_xyz[i + 1])          # padded coordinates of the new level: produced before its event
                     if SIDE_TABLES and sa.split is not None:
-                        tables[id(sa)] = sa.split.query_tables(l_xyz[i + 1], has_v0=False)
+                        tables[id(sa)] = sa.side_tables(sa_neigh[i], l_xyz[i + 1], False)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     ev_sa.append(ev)
                     lv = i + 1
                     for blk in ([self.enc_map[lv]] if lv < nlev else []) + [self.dec_map[lv]]:
                         if fm_key(lv, blk) not in fm_neigh:
-                            fm_neigh[fm_key(lv, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[lv], l_xyz[lv]))
+                            fm_neigh[fm_key(lv, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[lv], l_xyz[lv]), l_xyz[lv])
                         if SIDE_TABLES and blk.split is not None:
-                            tables[id(blk)] = blk.split.query_tables(l_xyz[lv], has_v0=True)
+                            tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(lv, blk)], l_xyz[lv], True)
                     ev_fm[lv] = torch.cuda.Event()
                     ev_fm[lv].record(side)
             for i in range(nlev + 1):
                 for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
                     if fm_key(i, blk) not in fm_neigh:
-                        fm_neigh[fm_key(i, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[i], l_xyz[i]))
+                        fm_neigh[fm_key(i, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[i], l_xyz[i]), l_xyz[i])
             mark("side:encoder_geometry_done")
             ev_all = torch.cuda.Event()                 # everything the encoder needs
             ev_all.record(side)
@@ -1623,7 +1686,8 @@ class FusedCloudConditionNet:
                 # per level above; here the rest: the level-0 decoder block and the feature-propagation blocks (used
                 # by the decoder, behind ev_knn)
                 if self.dec_map[0].split is not None:
-                    tables[id(self.dec_map[0])] = self.dec_map[0].split.query_tables(l_xyz[0], has_v0=True)
+                    tables[id(self.dec_map[0])] = self.dec_map[0].side_tables(fm_neigh[fm_key(0, self.dec_map[0])],
+                                                                              l_xyz[0], True)
                 for i in range(-1, -(len(self.fp) + 1), -1):
                     if self.fp[i].split is not None:
                         tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
@@ -1633,10 +1697,10 @@ class FusedCloudConditionNet:
                 for i in range(nlev + 1):
                     for blk in ([self.enc_map[i]] if 0 < i < nlev else []) + [self.dec_map[i]]:
                         if blk.split is not None:
-                            tables[id(blk)] = blk.split.query_tables(l_xyz[i], has_v0=True)
+                            tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(i, blk)], l_xyz[i], True)
                 for i, sa in enumerate(self.sa):
                     if sa.split is not None:
-                        tables[id(sa)] = sa.split.query_tables(l_xyz[i + 1], has_v0=False)
+                        tables[id(sa)] = sa.side_tables(sa_neigh[i], l_xyz[i + 1], False)
                 for i in range(-1, -(len(self.fp) + 1), -1):
                     if self.fp[i].split is not None:
                         tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
