@@ -779,11 +779,28 @@ __global__ __launch_bounds__(256) void weighted_moments_kernel(const float* __re
     const float lo = c >= relu_col0 ? 0.0f : -__builtin_inff();
     const float* yp = Y + (static_cast<long>(b) * rpb) * ldy + c;
     const float* wp = row_w + static_cast<long>(b) * rpb;
-    for (int r = r0; r < r1; ++r) {
-      const float f = fmaxf(yp[static_cast<long>(r) * ldy], lo);
-      const float w = wp[r];
-      s1 = __builtin_fmaf(w, f, s1);
-      s2 = __builtin_fmaf(w * f, f, s2);
+    // a launch of a few microseconds: every load of a thread in flight at once (a row loop of dependent-looking loads
+    // took 12 us), and no row of Y is read for a slice whose weights are all zero (sorted queries: the rule)
+    float w[32];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      w[k] = r0 + k < r1 ? wp[min(r0 + k, rpb - 1)] : 0.0f;
+      any = any || w[k] > 0.0f;
+    }
+    if (any) {
+#pragma unroll
+      for (int k0 = 0; k0 < 32; k0 += 16) {
+        float y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = yp[static_cast<long>(min(r0 + k0 + k, rpb - 1)) * ldy];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float f = fmaxf(y[k], lo);
+          s1 = __builtin_fmaf(w[k0 + k], f, s1);
+          s2 = __builtin_fmaf(w[k0 + k] * f, f, s2);
+        }
+      }
     }
   }
   red[sl][cl][0] = s1;

@@ -89,6 +89,12 @@ DEDUP_MIN_QUERIES = 64
 # block's per-query inputs (index rows, counts, coordinates, query features) are gathered in that order, its output
 # is gathered back.
 DEDUP_SORT = True
+# The query-independent half of the DECODER's feature-transfer blocks (first-conv statistics, shared MLP, value conv: it
+# needs coordinates, the static condition features and the step embeddings only) on the geometry stream once that
+# stream is done with the geometry (1.4 ms into the step), beside the encoder; the decoder then only runs the query /
+# score / pooling half.  (Round 3 measured such a hoist slower at 11.7 ms per step, every kernel filling the chip; with
+# one-point neighbourhoods evaluated once the launches are small.)
+AHEAD_DECODER_MAPS = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -1721,7 +1727,27 @@ class FusedCloudConditionNet:
         mark("main:embeddings_done")
 
         def transfer(blk, l, cl, query, V2=None):
+            if id(blk) in prepared:
+                prep, ev = prepared[id(blk)]
+                main.wait_event(ev)
+                return blk.finish(prep, query)
             return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
+
+        prepared = {}
+        if AHEAD_DECODER_MAPS and USE_SPLIT_FIRST and self.two_streams:
+            ev_emb = torch.cuda.Event()
+            ev_emb.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_emb)                     # the blocks' MLPs add the step / condition embeddings
+                saved_par, _PAR["stream"] = _PAR["stream"], None
+                for l in range(nlev, -1, -1):               # in the order the decoder will ask for them
+                    blk = self.dec_map[l]
+                    prep = blk.prepare(l_uvw[l], dec_cl[l], l_xyz[l], bank, subset=False,
+                                       neigh=fm_neigh[fm_key(l, blk)], V2=tables.get(id(blk)))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    prepared[id(blk)] = (prep, ev)
+                _PAR["stream"] = saved_par
 
         # ---- feature path ------------------------------------------------------------------------
         if ev_first is not None:
