@@ -94,6 +94,8 @@ DEDUP_SORT = True
 # stream is done with the geometry (1.4 ms into the step), beside the encoder; the decoder then only runs the query /
 # score / pooling half.  (Round 3 measured such a hoist slower at 11.7 ms per step, every kernel filling the chip; with
 # one-point neighbourhoods evaluated once the launches are small.)
+# (The same half of the ENCODER's blocks of levels >= 1 on a fourth stream, each as soon as its level's geometry exists:
+# 7.07 vs 6.46 ms -- it runs beside the sampling chain and the SA blocks that everything else waits for.  Removed.)
 AHEAD_DECODER_MAPS = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
@@ -1647,6 +1649,8 @@ class FusedCloudConditionNet:
             return (i % (nlev + 1), blk.radius, blk.nsample)
 
         ev_first = None
+        # (The first block's neighbourhoods on the MAIN stream, the geometry stream opening with the sampling chain that
+        # the first SA block now waits 0.14 ms for: 6.60 vs 6.46 ms.  Removed, as in round 3.)
         with torch.cuda.stream(side):
             mark("side:begin")
             fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].plan_ahead(self.enc_map[0].neighbours(l_uvw[0], xyz), xyz)
