@@ -312,6 +312,9 @@ _VARIANTS = [
     ("layerwise_condition_branch", {"PDR_FUSED_OPTS": "FUSE_CONDITION_BRANCH=0"}, False),
     ("torch_global_pointnet", {"PDR_FUSED_OPTS": "FUSE_GLOBAL_PNET=0"}, False),
     ("whole_neighbourhoods", {"PDR_FUSED_OPTS": "DEDUP=0"}, False),
+    ("unsorted_queries", {"PDR_FUSED_OPTS": "DEDUP_SORT=0"}, False),
+    ("dedup_from_256_queries", {"PDR_FUSED_OPTS": "DEDUP_MIN_QUERIES=256"}, False),
+    ("decoder_maps_in_place", {"PDR_FUSED_OPTS": "AHEAD_DECODER_MAPS=0"}, False),
 ]
 
 
