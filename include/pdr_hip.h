@@ -251,6 +251,10 @@ typedef struct {
    * (PDR_EUNSUPPORTED otherwise). */
   const int *tile_list;
   const int *n_tiles;
+  /* pooled launches (pdr_fused_layer_pool*): query q's pooled row is written to row out_rows[q] of `out` (NULL: row q)
+   * -- a block evaluated on sorted queries (pdr_dedup_sort) writes its output in the original order.  Wave-specialised
+   * tile shapes only. */
+  const int *out_rows;
   int partial_tpb;      /* rows of `partial` per batch element (0 = tiles_per_batch): tile t of batch element b
                          * writes row b * partial_tpb + t */
   int reserved_;
@@ -381,8 +385,9 @@ int pdr_dedup_plan(const int *idx, const int *counts, int B, int m, int K, int *
 /* Stable partition of every cloud's queries, those with more than one neighbour first: perm[b][j] = original index
  * of the query at sorted position j, inv = the inverse.  A block evaluated on its queries in that order (its per-query
  * inputs through pdr_gather_rows with perm, its output through pdr_gather_rows with inv) has its one-point
- * neighbourhoods in whole tiles. */
-int pdr_dedup_sort(const int *counts, int B, int m, int *perm, int *inv, pdr_stream_t stream);
+ * neighbourhoods in whole tiles.  perm_rows (NULL or (B,m)): b * m + perm[b][j], the same permutation as row numbers
+ * of a (B*m)-row tensor (pdr_layer_in_t.out_rows, pdr_patch_rows). */
+int pdr_dedup_sort(const int *counts, int B, int m, int *perm, int *inv, int *perm_rows, pdr_stream_t stream);
 /* pdr_gather_add over the tiles with tile_valid[tile] != 0 only (the others are neither read nor written); tile t
  * of batch element b writes row b * partial_tpb + t of `partial`. */
 int pdr_gather_add_tiles(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,
@@ -397,9 +402,11 @@ int pdr_gather_add_tiles(const float *U, int ldu, int n_src, const float *V, con
 int pdr_weighted_moments(const float *Y, int ldy, int B, int rpb, int C, int relu_col0, const float *row_w,
                          float *partial, int ptpb, int tpb_full, const unsigned char *tile_valid,
                          pdr_stream_t stream);
-/* out[q,:D] = act(V[q,:D] * vscale[b] + vshift[b]) for the rows q with row_w[q] > 0; other rows untouched. */
+/* out[r,:D] = act(V[q,:D] * vscale[b] + vshift[b]) for the rows q with row_w[q] > 0, r = out_rows[q] (NULL: q); other
+ * rows untouched. */
 int pdr_patch_rows(const float *V, int ldv, const float *vscale, const float *vshift, int v_relu,
-                   const float *row_w, int B, int rpb, int D, float *out, int ldo, pdr_stream_t stream);
+                   const float *row_w, int B, int rpb, int D, float *out, int ldo, const int *out_rows,
+                   pdr_stream_t stream);
 /* out (B,m,C) = src (B,n,C)[idx (B,m)] */
 int pdr_gather_rows(const float *src, const int *idx, int B, int n, int C, int m, float *out,
                     pdr_stream_t stream);

@@ -68,9 +68,9 @@ SIGNATURES = {
     "pdr_gather_add_tiles": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I,
                                   _P, _I, _P]),
     "pdr_dedup_plan": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "pdr_dedup_sort": (_I, [_P, _I, _I, _P, _P, _P]),
+    "pdr_dedup_sort": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "pdr_weighted_moments": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
-    "pdr_patch_rows": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "pdr_patch_rows": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
 }
 
 
@@ -84,7 +84,7 @@ class LayerIn(_c.Structure):
     _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("rseg", Seg),
                 ("add_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I), ("gidx", _P),
                 ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I),
-                ("gs1", _P), ("gs2", _P), ("tile_list", _P), ("n_tiles", _P), ("partial_tpb", _I),
+                ("gs1", _P), ("gs2", _P), ("tile_list", _P), ("n_tiles", _P), ("out_rows", _P), ("partial_tpb", _I),
                 ("reserved_", _I)]
 _lib = None
 

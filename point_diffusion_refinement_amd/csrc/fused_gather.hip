@@ -680,7 +680,8 @@ __global__ __launch_bounds__(1024) void dedup_compact_kernel(const unsigned char
 // one-point ones behind them.  perm[b][j] = original index of the query at sorted position j, inv = its inverse.
 // One workgroup per cloud; chunks of 1024 queries, two passes (real neighbourhoods, then the rest).
 __global__ __launch_bounds__(1024) void dedup_sort_kernel(const int* __restrict__ counts, int m,
-                                                         int* __restrict__ perm, int* __restrict__ inv) {
+                                                         int* __restrict__ perm, int* __restrict__ inv,
+                                                         int* __restrict__ perm_rows) {
   __shared__ int wtot[16];
   __shared__ int base_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(1024) void dedup_sort_kernel(const int* __restrict_
         const int j = base + woff + before;
         pb[j] = i;
         ib[i] = j;
+        if (perm_rows) perm_rows[static_cast<long>(blockIdx.x) * m + j] = static_cast<int>(blockIdx.x) * m + i;
       }
       __syncthreads();
       if (tid == 0) base_s = base + tot;
@@ -718,10 +720,11 @@ __global__ __launch_bounds__(1024) void dedup_sort_kernel(const int* __restrict_
 // counts (B, m) -> perm, inv (B, m) int32: see dedup_sort_kernel.  A block evaluated on its queries in `perm` order
 // (pdr_gather_rows of its per-query inputs) has its one-point neighbourhoods in whole tiles; pdr_gather_rows with
 // `inv` puts its output back.
-extern "C" int pdr_dedup_sort(const int* counts, int B, int m, int* perm, int* inv, pdr_stream_t stream) {
-  if (!counts || !perm || !inv || B < 0 || m <= 0) return PDR_EINVAL;
+extern "C" int pdr_dedup_sort(const int* counts, int B, int m, int* perm, int* inv, int* perm_rows,
+                              pdr_stream_t stream) {
+  if (!counts || !perm || !inv || B < 0 || m <= 0 || static_cast<long>(B) * m >= (1L << 31)) return PDR_EINVAL;
   if (B == 0) return PDR_OK;
-  hipLaunchKernelGGL(dedup_sort_kernel, dim3(B), dim3(1024), 0, pdr::as_stream(stream), counts, m, perm, inv);
+  hipLaunchKernelGGL(dedup_sort_kernel, dim3(B), dim3(1024), 0, pdr::as_stream(stream), counts, m, perm, inv, perm_rows);
   return pdr::check_launch();
 }
 
@@ -836,7 +839,8 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* __restrict
                                                          const float* __restrict__ vscale,
                                                          const float* __restrict__ vshift, int v_relu,
                                                          const float* __restrict__ row_w, int rpb, int D, long total,
-                                                         float* __restrict__ out, int ldo) {
+                                                         float* __restrict__ out, int ldo,
+                                                         const int* __restrict__ out_rows) {
   const long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (e >= total) return;
   const long q = e / D;
@@ -848,15 +852,16 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* __restrict
   const float h = vshift ? vshift[b * D + d] : 0.0f;
   v = __builtin_fmaf(v, s, h);
   if (v_relu) v = fmaxf(v, 0.0f);
-  out[q * ldo + d] = v;
+  out[(out_rows ? static_cast<long>(out_rows[q]) : q) * ldo + d] = v;
 }
 
 extern "C" int pdr_patch_rows(const float* V, int ldv, const float* vscale, const float* vshift, int v_relu,
-                              const float* row_w, int B, int rpb, int D, float* out, int ldo, pdr_stream_t stream) {
+                              const float* row_w, int B, int rpb, int D, float* out, int ldo, const int* out_rows,
+                              pdr_stream_t stream) {
   if (!V || !row_w || !out || B < 0 || rpb <= 0 || D <= 0 || ldv < D || ldo < D) return PDR_EINVAL;
   if (B == 0) return PDR_OK;
   const long total = static_cast<long>(B) * rpb * D;
   hipLaunchKernelGGL(patch_rows_kernel, dim3(blocks_for(total)), dim3(256), 0, pdr::as_stream(stream), V, ldv, vscale,
-                     vshift, v_relu, row_w, rpb, D, total, out, ldo);
+                     vshift, v_relu, row_w, rpb, D, total, out, ldo, out_rows);
   return pdr::check_launch();
 }

@@ -1200,7 +1200,7 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
       pdr::launch_fused_layer_ws(t.id, false, false, *in, Cin, Wt, ldw, bias, D, nullptr, 0, nullptr, D, nt, ncol, s,
                                  false, &pa))
     return pdr::check_launch();
-  if (in->tile_list) return PDR_EUNSUPPORTED;   // tile subsets: wave-specialised kernels only
+  if (in->tile_list || in->out_rows) return PDR_EUNSUPPORTED;   // tile subsets / row maps: wave-specialised kernels only
 #define PDR_LAUNCH_P(RT, CT, WR, WC, KC)                                                              \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false, true, false, true>), grid, dim3(256), \
                      0, s, *in, Cin, Wt, ldw, bias, D, static_cast<float*>(nullptr), 0,                   \

@@ -758,7 +758,10 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
                 }
                 l += __shfl_xor(l, 32, 64);
                 a += __shfl_xor(a, 32, 64);
-                if (hi_e == 0 && colok) pool.out[((rb + 8 * g) >> ksh) * pool.ldo + col] = a / l;
+                if (hi_e == 0 && colok) {
+                  const long q = (rb + 8 * g) >> ksh;                         // this query (uniform)
+                  pool.out[(in.out_rows ? static_cast<long>(in.out_rows[q]) : q) * pool.ldo + col] = a / l;
+                }
               }
             };
             if (K == 8) reduce(std::integral_constant<int, 1>());

@@ -232,8 +232,9 @@ class SortedQueries:
         dev = idx.device
         self.perm = torch.empty((B, m), dtype=torch.int32, device=dev)
         self.inv = torch.empty((B, m), dtype=torch.int32, device=dev)
+        self.perm_rows = torch.empty((B, m), dtype=torch.int32, device=dev)     # b m + perm: rows of a (B m)-row tensor
         _lib.check(_lib.load().pdr_dedup_sort(counts.data_ptr(), B, m, self.perm.data_ptr(), self.inv.data_ptr(),
-                                              _stream()), "dedup_sort")
+                                              self.perm_rows.data_ptr(), _stream()), "dedup_sort")
         # (rows of 32-bit words moved as they are: the row gather does no arithmetic)
         self.idx = gather_rows(idx.view(torch.float32), self.perm).view(torch.int32)
         self.counts = gather_rows(counts.view(B, m, 1).view(torch.float32), self.perm).view(torch.int32).view(B, m)
@@ -788,7 +789,7 @@ class FusedAttention:
         V, _, _, (vs, vt) = run_layer(h, self.v, fold=FoldReq(self.v_norm, self.D, npoint * K))
         return V, vs, vt
 
-    def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None):
+    def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None, sorted_q=None):
         """query: (B*npoint, Cq) tensor; h: Act (value input); key = Y1[:, key_col0:key_col0+C2];
         values: result of self.values(h, ...) when it was evaluated ahead of time."""
         lib = _lib.load()
@@ -819,6 +820,10 @@ class FusedAttention:
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
         dd = getattr(S1, "_dd", None)
         score_in.dd = dd                             # the pooled launch walks the block's tile subset
+        # a block evaluated on sorted queries (SortedQueries): the pooled launch and the patch write every query's row
+        # at its ORIGINAL place (out_rows); the unfused fallback below pools in sorted order and gathers back
+        fused_pool = FUSE_SCORE_POOL and K in (8, 16, 32) and (npoint * K) % 32 == 0 and self.D % 4 == 0
+        out_rows = sorted_q.perm_rows if (sorted_q is not None and dd is not None and fused_pool) else None
         # (a callable: the value half runs on another stream; calling it joins that stream into this one)
         V, vs, vt = values() if callable(values) else (values if values is not None else self.values(h, B, npoint, K))
         mark("  blk:joined", True)
@@ -832,12 +837,18 @@ class FusedAttention:
                 Vd = V._twin
                 _lib.check(lib.pdr_patch_rows(Vd.data_ptr(), Vd.shape[1], vsp, vtp, int(self.v_relu),
                                               dd.row_w.data_ptr(), B, npoint, self.D, out.data_ptr(), self.D,
-                                              _stream()), "patch_rows")
+                                              out_rows.data_ptr() if out_rows is not None else None, _stream()),
+                           "patch_rows")
+            if sorted_q is not None and out_rows is None:
+                # sorted queries whose rows were not placed by a row map (whole evaluation, unfused pooling)
+                return gather_rows(out.view(B, npoint, -1), sorted_q.inv).view(B * npoint, -1)
             return out
-        if FUSE_SCORE_POOL and K in (8, 16, 32) and (npoint * K) % 32 == 0 and self.D % 4 == 0:
+        if fused_pool:
             # last score conv + mask + softmax over K + weighted sum in ONE kernel: scores stay in the
             # MFMA accumulators
             li = score_in.struct()
+            if out_rows is not None:
+                li.out_rows = out_rows.data_ptr()     # sorted queries: pooled rows go back to their original places
             if _PRECISION[0] == "split_f16" and self.w2.Cin >= SPLIT_MIN_CIN and \
                     lib.pdr_fused_layer_variant(npoint * K, self.D) in SPLIT_VARIANTS:
                 # score conv on split-f16 arithmetic too (128-column tiles; else the exact kernel below)
@@ -1228,9 +1239,8 @@ class FusedGroupedBlock:
         if sq is not None:
             query_feats_cl = gather_rows(query_feats_cl, sq.perm)
         out = self.att(query_feats_cl.reshape(B * m, -1), prep["h"], prep["Y1"], prep["part1"], prep["tpb1"],
-                       self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"])
-        out = out.view(B, m, -1)
-        return gather_rows(out, sq.inv) if sq is not None else out
+                       self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"], sorted_q=sq)
+        return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
         B, m, _ = new_xyz.shape
@@ -1263,10 +1273,9 @@ class FusedGroupedBlock:
             return r
         values = _fork_join(B * m * K, chain_a)
         out = self.att(query_feats_cl.reshape(B * m, -1), None, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K,
-                       values=values)
+                       values=values, sorted_q=sq)
         mark("  blk:pool_done", True)
-        out = out.view(B, m, -1)
-        return gather_rows(out, sq.inv) if sq is not None else out
+        return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
 
 class FusedKnnFP:
@@ -1746,6 +1755,10 @@ class FusedCloudConditionNet:
                 saved_par, _PAR["stream"] = _PAR["stream"], None
                 for l in range(nlev, -1, -1):               # in the order the decoder will ask for them
                     blk = self.dec_map[l]
+                    if tables.get(id(blk)) is None:
+                        # (no per-query tables made on this stream: the block would evaluate them -- and pad its
+                        # coordinates through the per-forward xyz4 cache -- on two unordered streams)
+                        continue
                     prep = blk.prepare(l_uvw[l], dec_cl[l], l_xyz[l], bank, subset=False,
                                        neigh=fm_neigh[fm_key(l, blk)], V2=tables.get(id(blk)))
                     ev = torch.cuda.Event()

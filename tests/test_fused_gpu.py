@@ -1110,11 +1110,27 @@ def test_dedup_plan_tiles_and_weighted_moments_equal_the_whole_first_conv(cuda, 
     vs, vt = torch.rand(B, D, device=dev, generator=g) + 0.5, torch.randn(B, D, device=dev, generator=g)
     out = torch.full((B * m, D), 7.0, device=dev)
     _lib.check(lib.pdr_patch_rows(V.data_ptr(), D, vs.data_ptr(), vt.data_ptr(), 1, row_w.data_ptr(), B, m, D,
-                                  out.data_ptr(), D, st), "patch_rows")
-    want = torch.where((row_w > 0)[:, None], torch.relu(torch.addcmul(vt.repeat_interleave(m, 0), V,
-                                                                     vs.repeat_interleave(m, 0))),
-                       torch.full_like(out, 7.0))
+                                  out.data_ptr(), D, None, st), "patch_rows")
+    act = torch.relu(torch.addcmul(vt.repeat_interleave(m, 0), V, vs.repeat_interleave(m, 0)))
+    want = torch.where((row_w > 0)[:, None], act, torch.full_like(out, 7.0))
     assert ((out - want).abs() <= 1e-6 * (want.abs() + 1)).all()
+    # queries sorted per cloud, real neighbourhoods first, stable; inverse and row numbers; patched rows through a map
+    perm = torch.empty(B, m, dtype=torch.int32, device=dev)
+    inv, rows = torch.empty_like(perm), torch.empty_like(perm)
+    _lib.check(lib.pdr_dedup_sort(counts.data_ptr(), B, m, perm.data_ptr(), inv.data_ptr(), rows.data_ptr(), st),
+               "dedup_sort")
+    real = counts > 1
+    for b in range(B):
+        wantp = torch.cat([real[b].nonzero()[:, 0], (~real[b]).nonzero()[:, 0]]).int()
+        assert torch.equal(perm[b], wantp) and torch.equal(inv[b][perm[b].long()], torch.arange(m, device=dev).int())
+    assert torch.equal(rows, perm + (torch.arange(B, device=dev) * m).int()[:, None])
+    out2 = torch.full((B * m, D), 7.0, device=dev)
+    _lib.check(lib.pdr_patch_rows(V.data_ptr(), D, vs.data_ptr(), vt.data_ptr(), 1, row_w.data_ptr(), B, m, D,
+                                  out2.data_ptr(), D, rows.data_ptr(), st), "patch_rows")
+    want2 = torch.full_like(out2, 7.0)
+    sel = row_w > 0
+    want2[rows.view(-1)[sel].long()] = act[sel]
+    assert ((out2 - want2).abs() <= 1e-6 * (want2.abs() + 1)).all()
 
 
 @pytest.mark.parametrize("shape", [(4096, 32, 32, 0), (4096, 64, 128, 0), (2048, 128, 128, 32), (4096, 41, 32, 32)])
