@@ -81,9 +81,10 @@ LAB_SKIP_FOLD = False
 # the rule on x_t for most of a reverse process) are evaluated ONCE: the per-neighbour launches of a grouped block walk
 # only the 128-row tiles that contain a real neighbourhood (pdr_dedup_plan), a per-QUERY chain of the same layers
 # supplies the moments (x K) and the pooled rows of the others.  DESIGN.md section 4.7.  Blocks with fewer queries per
-# cloud than DEDUP_MIN_QUERIES run whole (same box: 256 -> 6.98 ms, 64 -> 6.84 / 6.88, 512 -> 7.35 / 7.37).
+# cloud than DEDUP_MIN_QUERIES run whole (same box: 512 -> 7.35 ms, 256 -> 6.98, 64 -> 6.84 / 6.88; later, with the
+# decoder halves hoisted, 64 -> 6.43 / 6.44, 16 -> 6.30: even the 16-query blocks, whose launches do next to nothing).
 DEDUP = True
-DEDUP_MIN_QUERIES = 64
+DEDUP_MIN_QUERIES = 16
 # ... on the block's queries SORTED per cloud, real neighbourhoods first (pdr_dedup_sort): a tile is walked when ANY of
 # its 4 queries has a real neighbourhood, so unsorted 14 % such queries keep 45 % of the tiles; sorted, 14 %.  The
 # block's per-query inputs (index rows, counts, coordinates, query features) are gathered in that order, its output
