@@ -22,6 +22,11 @@ condition features.  Anything else raises NotImplementedError at construction.
 The arithmetic is the reference's layer by layer (same GroupNorm definition, same injection
 points); only the summation order inside GEMMs / moments differs, as it does between any two
 BLAS back ends.
+
+What is NOT evaluated layer by layer the reference's way, with the same results: the first conv of a
+grouped block is split into per-point tables (SplitFirstConv), and a neighbourhood that ball_query filled with
+`nsample` copies of one point is evaluated once (Dedup / SortedQueries: the per-neighbour launches walk only the
+128-row tiles that hold a real neighbourhood, a per-query chain of the same layers stands in for the rest).
 """
 import ctypes
 
