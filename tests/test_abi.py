@@ -56,3 +56,26 @@ def test_cpu_tensors_are_rejected_not_emulated():
         _ext.furthest_point_sampling(x, 4)
     with pytest.raises(RuntimeError, match="CPU not supported"):
         _ext.ball_query(x, x, 0.1, 4)
+
+
+def test_dedup_entry_points_validate_their_arguments_without_a_gpu():
+    """pdr_dedup_plan / pdr_dedup_sort / pdr_weighted_moments / pdr_patch_rows / pdr_gather_add_tiles: argument errors
+    are return codes decided on the host (nothing is launched); an empty batch is a no-op."""
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+    p = 0x1000                                      # (never dereferenced: every call below returns before a launch)
+    EINVAL = _lib.PDR_EINVAL
+    assert lib.pdr_dedup_plan(p, p, 2, 64, 12, p, p, p, p, p, None) == EINVAL          # K not in {8, 16, 32}
+    assert lib.pdr_dedup_plan(p, p, 2, 3, 32, p, p, p, p, p, None) == EINVAL           # m K not a multiple of 128
+    assert lib.pdr_dedup_plan(None, p, 2, 64, 32, p, p, p, p, p, None) == EINVAL
+    assert lib.pdr_dedup_plan(p, p, 0, 64, 32, p, p, p, p, p, None) == _lib.PDR_OK
+    assert lib.pdr_dedup_sort(p, 2, 0, p, p, None, None) == EINVAL
+    assert lib.pdr_dedup_sort(p, 0, 64, p, p, None, None) == _lib.PDR_OK
+    assert lib.pdr_weighted_moments(p, 64, 2, 256, 64, 0, p, p, 65, 64, p, None) == EINVAL   # ptpb < tpb_full + 2
+    assert lib.pdr_weighted_moments(p, 32, 2, 256, 64, 0, p, p, 66, 64, p, None) == EINVAL   # ldy < C
+    assert lib.pdr_weighted_moments(p, 64, 0, 256, 64, 0, p, p, 66, 64, p, None) == _lib.PDR_OK
+    assert lib.pdr_patch_rows(p, 16, None, None, 1, p, 2, 64, 32, p, 32, None, None) == EINVAL   # ldv < D
+    assert lib.pdr_patch_rows(p, 32, None, None, 1, p, 0, 64, 32, p, 32, None, None) == _lib.PDR_OK
+    ga = (p, 64, 100, p, None, 64, p, None, None, None, None, None, 2, 256, 32, 64, None, 64, p, 0, 0, -1)
+    assert lib.pdr_gather_add_tiles(*ga, None, 4, None) == EINVAL                       # no tile flags
+    assert lib.pdr_gather_add_tiles(*ga, p, 1, None) == EINVAL                          # partial_tpb < tiles per cloud
