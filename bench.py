@@ -89,7 +89,7 @@ def self_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
-def build_sampler(device, use_graph, fused=True, precision="f32", single_stream=False):
+def build_sampler(device, use_graph, fused=True, precision="f32", single_stream=False, neighbourhoods="adaptive"):
     from point_diffusion_refinement_amd.pointnet2 import util
     from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG, ddpm_pointnet_config
     from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import \
@@ -103,7 +103,7 @@ def build_sampler(device, use_graph, fused=True, precision="f32", single_stream=
         from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
         model = FusedCloudConditionNet(net, precision=precision)
         model.two_streams = not single_stream
-    return GraphedReverseSampler(model, dh, noise='device', use_graph=use_graph), net
+    return GraphedReverseSampler(model, dh, noise='device', use_graph=use_graph, neighbourhoods=neighbourhoods), net
 
 
 def cpu_baseline(budget_s):
@@ -210,6 +210,17 @@ def config3_eval(device, cpu_seconds):
             passes += 1
         out[name + "_pairs_per_s"] = round(passes * pairs / (time.perf_counter() - t0), 1)
         out[name + "_timed_passes"] = passes
+    # the 1000-pair EMD batches against the C oracle on 8 pairs spread over a batch (first / middle / last: the kernels
+    # stride pairs over the grid, emd_kernel.cu:41,174-196 `for i = blockIdx.x; i < b; i += gridDim.x`), north_star's 1e-4
+    probe_pairs = [0, 1, nb // 3, nb // 2, nb // 2 + 1, 2 * nb // 3, nb - 2, nb - 1]
+    emd_gpu = emd.earth_mover_distance(a, b).cpu().numpy()
+    an_, bn_ = a.cpu().numpy(), b.cpu().numpy()
+    from concurrent.futures import ThreadPoolExecutor as _Pool
+    with _Pool(len(probe_pairs)) as _ex:                    # (~9 s per pair on one core: all eight at once)
+        emd_ref = np.array(list(_ex.map(lambda i: float(O.emd(an_[i:i + 1], bn_[i:i + 1])[0]), probe_pairs)))
+    np.testing.assert_allclose(emd_gpu[probe_pairs], emd_ref, rtol=1e-4)
+    out["emd_checked_pairs"] = {"pairs_of_a_1000_pair_batch": probe_pairs, "rtol": 1e-4,
+                                "max_rel": float(np.abs(emd_gpu[probe_pairs] / emd_ref - 1).max())}
     out["chamfer_valu_tflops"] = round(out["chamfer_f1_pairs_per_s"] * 2 * n * n * 8 / 1e12, 2)
     out["emd_texp_per_s"] = round(out["emd_pairs_per_s"] * 30 * n * n / 1e12, 3)
     # CPU: the scalar C oracle, one pair per call, calls spread over a thread pool of one worker per PHYSICAL core
@@ -316,6 +327,13 @@ def dry_main(args, world, rank):
         print(json.dumps({"metric": "DDPM reverse steps/sec (T=1000, N=2048)", "dry": True, "n_gpus": world,
                           "value": round(world * B * args.steps / elapsed, 2), "steps": args.steps,
                           "ranks_seen": int(sum(1 for c in counts if c > 0)), "records_gathered": int(allrec.shape[0]),
+                          "world_size_after_gather": dist.get_world_size() if world > 1 else 1,
+                          "records_per_rank": [int(c) for c in counts],
+                          # rank order of the concatenation (generate_samples_distributed.py:84-95): the rank column of
+                          # the gathered records, run-length encoded
+                          "record_rank_runs": [[r, int((allrec[:, 4] == r).sum())] for r in
+                                               sorted(set(allrec[:, 4].tolist()))],
+                          "rank_column_sorted": bool((allrec[1:, 4] >= allrec[:-1, 4]).all()),
                           "record_rank_column": sorted(set(allrec[:, 4].tolist()))}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -411,14 +429,21 @@ def main():
                    **({"single_stream": True} if args.single_stream else {}),
                    "execution": "layer-by-layer torch + native ops" if args.unfused else "fused channel-last HIP",
                    **({} if args.unfused else
-                      {"neighbourhoods": "K identical rows of a <= 1-point ball evaluated once (results unchanged; "
-                                         "see one_point_neighbourhoods for the share walked and the whole evaluation)"})},
+                      {"neighbourhoods": "K identical rows of a <= 1-point ball evaluated once where the sampler's "
+                                         "per-step probe says it pays (results unchanged; see step_form, "
+                                         "one_point_neighbourhoods, trajectory)"})},
         "completed_points_per_s_per_gpu": round(value / world * N_POINTS / T_STEPS, 2),
         "first_uncached_step_ms": round(first_step_s * 1e3, 2),
-        # (the REFERENCE's GEMM work per cloud-step / time: an equivalent rate -- the executed flops are fewer: split first
-        # conv, one-point neighbourhoods evaluated once)
-        "gemm_tflops": round(value * GEMM_GFLOP_PER_CLOUD_STEP / 1e3, 2),
+        # the REFERENCE's GEMM work per cloud-step (26.35 GFLOP) / time: an equivalent rate, NOT an achieved
+        # one -- the executed flops are fewer (`executed_work` below)
+        "reference_equivalent_tflops": round(value * GEMM_GFLOP_PER_CLOUD_STEP / 1e3, 2),
+        "step_form": {"sampler": getattr(sampler, "neighbourhoods", None),
+                      "replayed": dict(getattr(sampler, "mode_counts", {})),
+                      "tiles_walked_frac": None if getattr(sampler, "walked_share", None) is None
+                      else round(sampler.walked_share, 4)},
         "ranks_seen": int(sum(1 for c in counts if c > 0)), "records_gathered": int(allrec.shape[0]),
+        # (after the gather: the collective's own view of the job -- the first real N-GPU run verifies itself)
+        "world_size_after_gather": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
         "metric_gather": {"collective": "all_gather of (n,5) f32 records [cd_t, cd_p, f1, emd, label]",
                           "backend": "nccl (RCCL)" if world > 1 else "none (1 rank)",
                           "eval_plus_gather_ms": round(gather_s * 1e3, 2),
@@ -434,37 +459,26 @@ def main():
         except Exception as e:  # never lose the headline number to an instrumentation problem
             out["roofline"] = {"error": repr(e)}
     if solo and not args.no_extras and not args.unfused:
-        # The headline evaluates neighbourhoods that are K copies of one row ONCE (fused_network.DEDUP):
-        # x_T and the x_t of this benchmark are noise, as they are for most of a reverse process, so most balls hold at
-        # most one point.  Reported next to it: how much of the per-neighbour tile work the headline walked, and the
-        # same step with every neighbourhood evaluated in full (the cost on ANY input, e.g. a finished surface).
+        # The headline evaluates neighbourhoods that are K copies of one row ONCE (fused_network.DEDUP) where
+        # that pays: x_T and the x_t of this benchmark are noise, as they are for most of a reverse process, so most balls
+        # hold at most one point and the sampler's per-step switch (reverse_sampler.py) replays the deduplicated step.
+        # Reported next to it: the share of the per-neighbour tile work the step walked, the same step with every
+        # neighbourhood evaluated (the cost of ANY input under the switch, + its probe), the executed GEMM work of both
+        # forms, and -- `trajectory` -- both forms along a trajectory that ends on a surface.
         try:
-            from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
-            plans, init = [], FN.Dedup.__init__
-
-            def rec(self, *a, **k):
-                init(self, *a, **k)
-                plans.append(self)
-            FN.Dedup.__init__ = rec
-            try:
-                s3, _ = build_sampler(device, False, precision=args.precision)
-                s3.begin((B, N_POINTS, 3), cond, label, x_T=x_T)
-                plans.clear()
-                s3.advance(1)
-                torch.cuda.synchronize(device)
-                walked = sum(int(p.n_tiles) for p in plans) / max(1.0, float(sum(p.B * p.tpb for p in plans)))
-            finally:
-                FN.Dedup.__init__ = init
-            del s3
-            FN.DEDUP = False
-            try:
-                s4, _ = build_sampler(device, not args.no_graph, precision=args.precision)
-                el4, _ = timed_steps(s4, args.steps, args.warmup)
-            finally:
-                FN.DEDUP = True
+            from tools.kernel_roofline import executed_gflop_per_step
+            s4, _ = build_sampler(device, not args.no_graph, precision=args.precision, neighbourhoods="whole")
+            el4, _ = timed_steps(s4, args.steps, args.warmup)
+            ex = {}
+            for mode in ("once", "whole"):
+                g = executed_gflop_per_step(s4, mode)
+                ms = ms_per_step if mode == "once" else el4 / args.steps * 1e3
+                ex[mode] = {"executed_gflop_per_step": round(g, 1), "ms_per_step": round(ms, 4),
+                            "executed_tflops": round(g / ms, 2), "step_mfma_frac": round(g / ms / 157.3, 4)}
             del s4
             out["one_point_neighbourhoods"] = {
-                "evaluated_once": True, "tiles_walked_frac": round(walked, 3),
+                "evaluated_once": sampler.mode_counts.get("once", 0) > 0,
+                "tiles_walked_frac": out["step_form"]["tiles_walked_frac"],
                 "whole_evaluation": {"value": round(B * args.steps / el4, 2), "unit": "cloud-steps/s",
                                      "ms_per_step": round(el4 / args.steps * 1e3, 4)},
                 "note": "ball_query pads a neighbourhood with its first hit: a query with <= 1 point in its ball "
@@ -472,9 +486,43 @@ def main():
                         "such queries only are skipped by the per-neighbour launches; a per-query chain supplies their "
                         "GroupNorm moments (x K) and pooled rows -- same results (tests/test_fused_gpu.py::"
                         "test_one_point_neighbourhoods_*, the reference goldens).  tiles_walked_frac: share of the "
-                        "deduplicated blocks' tiles this input needed; whole_evaluation: the step with nothing skipped"}
+                        "deduplicated blocks' tiles this input needed; whole_evaluation: the step with nothing skipped "
+                        "(what the sampler replays when the walked share exceeds its threshold)"}
+            out["executed_work"] = {
+                "headline_step": ex["once"], "whole_evaluation": ex["whole"],
+                "reference_gflop_per_step": round(B * GEMM_GFLOP_PER_CLOUD_STEP, 1),
+                "note": "sum over the layer launches of one step of 2 rows_walked Cin Cout (tools/kernel_roofline."
+                        "executed_gflop_per_step); step_mfma_frac = executed TFLOP/s / 157.3 (fp32 MFMA peak): the "
+                        "whole-step fraction next to roofline.frac of the dominant kernel"}
         except Exception as e:
             out["one_point_neighbourhoods"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            from tools import trajectory
+            from point_diffusion_refinement_amd.pointnet2 import util
+            from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG
+
+            def fast():
+                from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedFastSampler
+                smp, _ = build_sampler(device, True, precision=args.precision)
+                dh = util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG)
+                return GraphedFastSampler(smp.net, dh, DIFFUSION_CONFIG, length=50, sampling_method='var',
+                                          schedule='quadratic', kappa=0.5, noise='device', use_graph=True)
+
+            def refine():
+                from point_diffusion_refinement_amd.pointnet2.configs import refinement_pointnet_config
+                from point_diffusion_refinement_amd.pointnet2.fused_network import FusedCloudConditionNet
+                from point_diffusion_refinement_amd.pointnet2.models.pointnet2_with_pcld_condition import \
+                    PointNet2CloudCondition
+                torch.manual_seed(0)
+                return FusedCloudConditionNet(PointNet2CloudCondition(refinement_pointnet_config(8)).eval().to(device),
+                                              precision=args.precision)
+            out["trajectory"] = trajectory.measure(
+                lambda: build_sampler(device, True, precision=args.precision)[0], fast, refine, device, B,
+                util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG))
+        except Exception as e:
+            out["trajectory"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if solo and not args.no_extras and not args.unfused and args.precision == "f32":
         try:
             s2, _ = build_sampler(device, not args.no_graph, precision="split_f16")

@@ -257,6 +257,18 @@ typedef struct {
   const int *out_rows;
   int partial_tpb;      /* rows of `partial` per batch element (0 = tiles_per_batch): tile t of batch element b
                          * writes row b * partial_tpb + t */
+  /* WEIGHTED statistics (per-query launches of a deduplicated block, round 5): NULL, or (B) ints -- only the rows
+   * r >= wrow0[b] of batch element b (r = row within the batch element) count in `partial`, and the tile's moments
+   * are multiplied by wmul (the K copies each such row stands for).  Y is written for every row. */
+  float wmul;
+  const int *wrow0;
+  /* pooled launches (pdr_fused_layer_pool*): NULL, or the per-QUERY value rows (P / K, patch_ld) of a deduplicated
+   * block -- before it walks its tiles the launch writes out[out_rows ? out_rows[q] : q, :] = act(patch_values[q, :] *
+   * vscale + vshift) for every query q with patch_w[q] > 0 (= pdr_patch_rows, without its launch).  Wave-specialised
+   * tile shapes only; D, patch_ld and ldo multiples of 4. */
+  const float *patch_values;
+  const float *patch_w;
+  int patch_ld;
   int reserved_;
 } pdr_layer_in_t;
 
@@ -324,11 +336,14 @@ int pdr_fused_layer_pool_f16x3(const pdr_layer_in_t *in, long P, int Cin, const 
  * `partial` points at the first of C columns inside rows of ldp columns */
 int pdr_gn_reduce(const float *partial, int ldp, int B, int tiles_per_batch, int C, double mult,
                   double *chan_stats, int Ctot, int coff, pdr_stream_t stream);
-/* pdr_gn_reduce (x1 or x2 sources) + pdr_gn_finalize in one launch; part1 may be NULL */
+/* pdr_gn_reduce (x1 or x2 sources) + pdr_gn_finalize in one launch; part1 may be NULL.
+ * nvalidX (NULL, or (B) ints) / tpb_mainX: source X was produced by a tile SUBSET (pdr_layer_in_t.tile_list on sorted
+ * queries, pdr_dedup_prepare): of the first tpb_mainX partial rows of batch element b only the first nvalidX[b] were
+ * written and only those are summed; rows >= tpb_mainX (the per-query rows' weighted moments) always count. */
 int pdr_gn_fold(const float *part0, int ldp0, int tpb0, int C0, double mult0, const float *part1,
                 int ldp1, int tpb1, int C1, double mult1, int B, int Cn, int G, double n, float eps,
-                const float *gamma, const float *beta, float *scale, float *shift,
-                pdr_stream_t stream);
+                const float *gamma, const float *beta, float *scale, float *shift, const int *nvalid0,
+                int tpb_main0, const int *nvalid1, int tpb_main1, pdr_stream_t stream);
 /* out (P,C; ld ldo) = prologue(X): materialise an activation descriptor */
 int pdr_apply_act(const pdr_layer_in_t *in, long P, int C, float *out, int ldo,
                   pdr_stream_t stream);
@@ -382,6 +397,21 @@ int pdr_gather_add(const float *U, int ldu, int n_src, const float *V, const flo
  * valid row-tile numbers, ascending) and n_tiles (1).  K in {8,16,32}, m*K a multiple of 128. */
 int pdr_dedup_plan(const int *idx, const int *counts, int B, int m, int K, int *idx0, float *row_w,
                    unsigned char *tile_valid, int *tile_list, int *n_tiles, pdr_stream_t stream);
+/* pdr_dedup_sort + pdr_gather_rows of the ball query's index rows / counts / query coordinates into the sorted order +
+ * pdr_dedup_plan on the sorted arrays, in ONE launch (round 5; same values): perm, inv, perm_rows (B,m) as
+ * pdr_dedup_sort; idx_s (B,m,K), counts_s (B,m), xyz_s (B,m,3; xyz may be NULL) the inputs in that order; idx0, row_w,
+ * tile_valid, tile_list, n_tiles as pdr_dedup_plan; nvalid (2 B ints): [b] = valid tiles of cloud b -- with sorted
+ * queries its FIRST nvalid[b] tiles --, [B + b] = nvalid[b] * (128 / K) = the first query of its skipped tiles
+ * (pdr_layer_in_t.wrow0 of the per-query launches, pdr_gn_fold's nvalid); probe_acc (NULL or 2 ints, accumulated with
+ * atomics): [0] += sum_b nvalid[b], [1] += B m K / 128.  B <= 1024, idx / idx_s 16-byte aligned. */
+int pdr_dedup_prepare(const int *idx, const int *counts, const float *xyz, int B, int m, int K, int *perm, int *inv,
+                      int *perm_rows, int *idx_s, int *counts_s, float *xyz_s, int *idx0, float *row_w,
+                      unsigned char *tile_valid, int *tile_list, int *n_tiles, int *nvalid, int *probe_acc,
+                      pdr_stream_t stream);
+/* the probe counters of pdr_dedup_prepare without the plan: probe_acc[0] += the tiles a plan of these ball counts
+ * would walk, [1] += B m K / 128 (the step with every neighbourhood evaluated carries it, so that the sampler can
+ * tell which of its two captured steps the next x_t wants: reverse_sampler.py) */
+int pdr_dedup_probe(const int *counts, int B, int m, int K, int *probe_acc, pdr_stream_t stream);
 /* Stable partition of every cloud's queries, those with more than one neighbour first: perm[b][j] = original index
  * of the query at sorted position j, inv = the inverse.  A block evaluated on its queries in that order (its per-query
  * inputs through pdr_gather_rows with perm, its output through pdr_gather_rows with inv) has its one-point
@@ -395,6 +425,16 @@ int pdr_gather_add_tiles(const float *U, int ldu, int n_src, const float *V, con
                          const float *s2, const float *r2, int B, int rows_per_batch, int K, int Cout,
                          float *Y, int ldy, float *partial, int relu_col0, int ycol0, int ycols,
                          const unsigned char *tile_valid, int partial_tpb, pdr_stream_t stream);
+/* pdr_gather_add_tiles + the block's per-QUERY rows in the same launch (round 5: was a K = 1 pdr_gather_add on the
+ * first neighbours + pdr_weighted_moments): Yd (B*m, ldyd) <- U[b, idx0[q]] + V[q] (empty ball: V0[q]), every column,
+ * m = rows_per_batch / K; partial row b*partial_tpb + tiles_per_batch + j <- wmul x the moments of the rows
+ * q >= wrow0[b] of the j-th group of 128 queries of cloud b.  Ball form (no s1 / s2);
+ * partial_tpb >= tiles_per_batch + ceil(m / 128). */
+int pdr_gather_add_tiles_twin(const float *U, int ldu, int n_src, const float *V, const float *V0, int ldv,
+                              const int *idx, const int *counts, int B, int rows_per_batch, int K, int Cout, float *Y,
+                              int ldy, float *partial, int relu_col0, int ycol0, int ycols,
+                              const unsigned char *tile_valid, int partial_tpb, const int *idx0, float *Yd, int ldyd,
+                              const int *wrow0, float wmul, pdr_stream_t stream);
 /* Moments of a materialised (B*rpb, C) tensor with one weight per row, appended to the moments of a tile subset:
  * partial row b*ptpb + tpb_full + j  <-  sum_r w[r] f, sum_r w[r] f^2 over the rows r of 128-row tile j of batch
  * element b (f = y, columns >= relu_col0: max(y,0)); partial rows b*ptpb + t (t < tpb_full) of the tiles with
@@ -432,6 +472,14 @@ int pdr_reverse_update(float *x, const float *eps, int ld_eps, const float *z, c
 int pdr_reverse_step(float *x, const float *eps, int ld_eps, const float *z, const float *tab_a,
                      const float *tab_b, const float *tab_c, long long *t_dev, const float *ts_table,
                      float *ts_out, unsigned long long *rng_state, int *ticket, long npoints, int mode,
+                     int *probe_acc, int *probe_out, pdr_stream_t stream);
+/* (probe_acc / probe_out, both NULL or both set: the same last workgroup copies the two probe counters of this step
+ * (pdr_dedup_prepare / pdr_dedup_probe) to probe_out -- device-visible pinned host memory: the sampler reads them a
+ * step or two later to pick the captured step for the next x_t -- and zeroes probe_acc for the next step.) */
+/* out (B, W; ld ldo) = row clamp(*t_dev, 0, T-1) of table (T, W; ld ldt), broadcast to B rows: one reverse step's
+ * per-block step-embedding rows fc(t_emb) looked up in a table built once per schedule with pdr_embed_linear over all T
+ * step values (the chain depends on t only; same bits as evaluating it per step).  W, ldt, ldo multiples of 4. */
+int pdr_embed_select(const float *table, int ldt, int T, const long long *t_dev, int B, int W, float *out, int ldo,
                      pdr_stream_t stream);
 /* ---- step embedding chain -------------------------------------------------------
  * out (B,N; ld ldo) = act(bias + in . W^T), W (N,K) row-major as nn.Linear stores it, act 0 = none, 1 = swish

@@ -52,14 +52,19 @@ SIGNATURES = {
     "pdr_apply_act": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
     "pdr_act_colmax": (_I, [_P, _c.c_long, _I, _P, _P]),
     "pdr_gn_fold": (_I, [_P, _I, _I, _I, _c.c_double, _P, _I, _I, _I, _c.c_double, _I, _I, _I, _c.c_double, _F,
-                         _P, _P, _P, _P, _P]),
+                         _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "pdr_gn_finalize": (_I, [_P, _I, _I, _I, _I, _c.c_double, _F, _P, _P, _P, _P, _P]),
     "pdr_group_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_knn_build": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pdr_attention_pool": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_gather_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "pdr_reverse_update": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
-    "pdr_reverse_step": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
+    "pdr_reverse_step": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_long, _I, _P, _P, _P]),
+    "pdr_embed_select": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "pdr_dedup_prepare": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pdr_dedup_probe": (_I, [_P, _I, _I, _I, _P, _P]),
+    "pdr_gather_add_tiles_twin": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I,
+                                       _P, _P, _I, _P, _F, _P]),
     "pdr_gather_rows2": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "pdr_pad_rows": (_I, [_P, _c.c_long, _I, _P, _I, _P]),
     "pdr_mark_time": (_I, [_P, _P]),
@@ -85,6 +90,7 @@ class LayerIn(_c.Structure):
                 ("add_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I), ("gidx", _P),
                 ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I),
                 ("gs1", _P), ("gs2", _P), ("tile_list", _P), ("n_tiles", _P), ("out_rows", _P), ("partial_tpb", _I),
+                ("wmul", _F), ("wrow0", _P), ("patch_values", _P), ("patch_w", _P), ("patch_ld", _I),
                 ("reserved_", _I)]
 _lib = None
 

@@ -93,7 +93,35 @@ __global__ __launch_bounds__(256) void embed_linear_kernel(const float* __restri
   }
 }
 
+// out[b, :W] = table[clamp(*t, 0, T - 1), :W] for every b < B (16-byte pieces)
+__global__ __launch_bounds__(256) void embed_select_kernel(const float* __restrict__ table, int ldt, int T,
+                                                           const long long* __restrict__ t_dev, int B, int W4,
+                                                           float* __restrict__ out, int ldo) {
+  long long t = *t_dev;
+  t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+  const float4* row = reinterpret_cast<const float4*>(table + t * ldt);
+  const int total = B * W4;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int b = e / W4, c = e - b * W4;
+    *reinterpret_cast<float4*>(out + static_cast<long>(b) * ldo + 4 * c) = row[c];
+  }
+}
+
 }  // namespace
+
+extern "C" int pdr_embed_select(const float* table, int ldt, int T, const long long* t_dev, int B, int W, float* out,
+                                int ldo, pdr_stream_t stream) {
+  if (!table || !t_dev || !out || T <= 0 || B < 0 || W <= 0 || ldt < W || ldo < W) return PDR_EINVAL;
+  if (W % 4 || ldt % 4 || ldo % 4 || (reinterpret_cast<uintptr_t>(table) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return PDR_EUNSUPPORTED;
+  if (B == 0) return PDR_OK;
+  const long total = static_cast<long>(B) * (W / 4);
+  if (total >= (1L << 31)) return PDR_EINVAL;
+  const unsigned blocks = static_cast<unsigned>((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(embed_select_kernel, dim3(blocks), dim3(256), 0, pdr::as_stream(stream), table, ldt, T, t_dev, B,
+                     W / 4, out, ldo);
+  return pdr::check_launch();
+}
 
 extern "C" int pdr_embed_linear(const float* x, int ldx, const float* ts, int ts_stride, const float* freq,
                                 int half, const float* W, const float* bias, int B, int K, int N, int act,

@@ -469,6 +469,24 @@ extern "C" int pdr_furthest_point_sampling(const float* xyz, int B, int N, int m
   static_assert(kMaxResidentN >= 12288, "resident path must cover the LDS-resident range");
 #define PDR_FPS_CASE(T, PPT) \
   if (N <= (T) * (PPT)) return launch_resident<T, PPT>(xyz, B, N, m, R, Rbits, Q, idx, s)
+  // PDR_FPS_THREADS (process-wide, read once; lab A/B, round 5): 512 / 1024 threads per cloud for N <= 4096 -- fewer
+  // points per thread (a shorter update chain per round) against a wider exchange (8 / 16 wave entries per round)
+  static const int fps_threads = []() {
+    const char* e = getenv("PDR_FPS_THREADS");
+    const int v = e ? atoi(e) : 256;
+    return (v == 512 || v == 1024) ? v : 256;
+  }();
+  if (fps_threads == 512 && N <= 4096) {
+    PDR_FPS_CASE(512, 1);
+    PDR_FPS_CASE(512, 2);
+    PDR_FPS_CASE(512, 4);
+    PDR_FPS_CASE(512, 8);
+  }
+  if (fps_threads == 1024 && N <= 4096) {
+    PDR_FPS_CASE(1024, 1);
+    PDR_FPS_CASE(1024, 2);
+    PDR_FPS_CASE(1024, 4);
+  }
   PDR_FPS_CASE(64, 1);
   PDR_FPS_CASE(64, 2);
   PDR_FPS_CASE(256, 1);

@@ -413,10 +413,21 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
     const float* __restrict__ U, int ldu, int n_src, const float* __restrict__ V,
     const float* __restrict__ V0, int ldv, const int* __restrict__ idx, const int* __restrict__ counts,
     const float* __restrict__ s1, const float* __restrict__ r1, const float* __restrict__ s2,
-    const float* __restrict__ r2, int rows_per_batch, int K, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int ycol0, int ycol1,
-    const unsigned char* __restrict__ tile_valid, int partial_tpb) {
+    const float* __restrict__ r2, int rows_per_batch_, int K_, int Cout, float* __restrict__ Y_, int ldy_,
+    float* __restrict__ partial, int relu_col0, int ycol0_, int ycol1_,
+    const unsigned char* __restrict__ tile_valid, int partial_tpb, pdr::GatherTwin tw) {
   constexpr int TM = 128;
+  // TWIN blocks (blockIdx.x >= tw.n_main; round 5): the same sum over the block's per-QUERY rows -- neighbour = the
+  // query's first one (tw.idx0), K = 1 -- written whole to tw.Y, with the GroupNorm moments of the rows q >= wrow0[b]
+  // (the queries of the cloud's skipped tiles) times tw.wmul in partial row b partial_tpb + tiles_per_batch + tile:
+  // what a separate K = 1 launch + pdr_weighted_moments produced, in the launch that walks the tile subset.
+  const bool twin = static_cast<int>(blockIdx.x) >= tw.n_main && tw.n_main > 0;   // uniform
+  const int rows_per_batch = twin ? rows_per_batch_ / K_ : rows_per_batch_;
+  const int K = twin ? 1 : K_;
+  const int* __restrict__ idx_e = twin ? tw.idx0 : idx;
+  float* __restrict__ Y = twin ? tw.Y : Y_;
+  const int ldy = twin ? tw.ldy : ldy_;
+  const int ycol0 = twin ? 0 : ycol0_, ycol1 = twin ? ((Cout + 3) & ~3) : ycol1_;
   constexpr int RPI = 64 / LPR;            // rows per wave instruction
   // row groups in flight per iteration: the kernel is bound by the latency of its L2 gathers, so every wave keeps
   // DEPTH x 2 independent 16-byte loads outstanding (4 measured against 2: see DESIGN.md)
@@ -426,18 +437,24 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, cl = lane % LPR;
   const int tpb = (rows_per_batch + TM - 1) / TM;
-  const int bid = pdr::xcd_contiguous(blockIdx.x, gridDim.x);
+  const int n_main = tw.n_main > 0 ? tw.n_main : static_cast<int>(gridDim.x);
+  const int bid = twin ? static_cast<int>(blockIdx.x) - n_main : pdr::xcd_contiguous(blockIdx.x, n_main);
   const int b = bid / tpb, tb = bid - b * tpb;
   // a tile subset (pdr_dedup_plan): the other tiles are neither read nor written
-  if (tile_valid && !tile_valid[bid]) return;   // uniform
-  const long prow = static_cast<long>(b) * (partial_tpb > 0 ? partial_tpb : tpb) + tb;   // the tile's partial row
+  if (!twin && tile_valid && !tile_valid[bid]) return;   // uniform
+  const int tpb_main = (rows_per_batch_ + TM - 1) / TM;
+  // the tile's partial row (twin tiles behind the cloud's main tiles)
+  const long prow = static_cast<long>(b) * (partial_tpb > 0 ? partial_tpb : tpb) + (twin ? tpb_main : 0) + tb;
   const long row0 = static_cast<long>(b) * rows_per_batch + static_cast<long>(tb) * TM;
   const int nvalid = min(TM, rows_per_batch - tb * TM);
+  // statistics: rows >= wlo of the tile count (twin: the queries behind the cloud's valid tiles), times wmul
+  const int wlo = twin ? min(max(tw.wrow0[b] - tb * TM, 0), TM) : 0;   // uniform
+  const float wmul = twin ? tw.wmul : 1.0f;
   const float* Ub = U + static_cast<long>(b) * n_src * ldu;
   const int wr0 = wave * 32;
   const int myr = min(wr0 + (lane & 31), nvalid - 1);
   const long myp = row0 + myr;
-  const int my_idx = idx[myp];
+  const int my_idx = idx_e[myp];
   const int my_empty = (counts && counts[myp / K] <= 0) ? 1 : 0;
   const float my_s1 = s1 ? s1[myp] : 0.0f;
   const float my_s2 = s2 ? s2[myp] : 0.0f;
@@ -503,12 +520,14 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
           }
           if (ywin) *reinterpret_cast<float4*>(Y + (row0 + wr0 + rr[k]) * ldy + (c - ycol0)) = y;
           const float e[4] = {y.x, y.y, y.z, y.w};
+          if (wr0 + rr[k] >= wlo) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float f;
-            asm("v_max_f32 %0, %1, %2" : "=v"(f) : "v"(e[j]), "v"(lo[j]));   // max(y, 0) or y (bound -inf)
-            a1[j] += f;
-            a2[j] = __builtin_fmaf(f, f, a2[j]);
+            for (int j = 0; j < 4; ++j) {
+              float f;
+              asm("v_max_f32 %0, %1, %2" : "=v"(f) : "v"(e[j]), "v"(lo[j]));   // max(y, 0) or y (bound -inf)
+              a1[j] += f;
+              a2[j] = __builtin_fmaf(f, f, a2[j]);
+            }
           }
         }
       }
@@ -538,8 +557,8 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
         const float t2 = (red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) +
                          (red[2][threadIdx.x][1] + red[3][threadIdx.x][1]);
         float* o = partial + (prow * Cout + cc2) * 2;
-        o[0] = t1;
-        o[1] = t2;
+        o[0] = t1 * wmul;      // (x 1.0f outside the twin tiles: exact)
+        o[1] = t2 * wmul;
       }
       __syncthreads();
     }
@@ -554,7 +573,8 @@ static int gather_add_impl(const float* U, int ldu, int n_src, const float* V, c
                            const float* r1, const float* s2, const float* r2, int B,
                            int rows_per_batch, int K, int Cout, float* Y, int ldy, float* partial,
                            int relu_col0, int ycol0, int ycols, const unsigned char* tile_valid, int partial_tpb,
-                           pdr_stream_t stream) {
+                           pdr_stream_t stream, const int* idx0 = nullptr, float* Yd = nullptr, int ldyd = 0,
+                           const int* wrow0 = nullptr, float wmul = 1.0f) {
   if (!U || !V || !idx || (!Y && !partial) || B < 0 || rows_per_batch <= 0 || K <= 0 || Cout <= 0 ||
       n_src <= 0)
     return PDR_EINVAL;
@@ -571,14 +591,26 @@ static int gather_add_impl(const float* U, int ldu, int n_src, const float* V, c
   if (!al(U) || !al(V) || (V0 && !al(V0)) || (Y && !al(Y)) || (r1 && !al(r1)) || (r2 && !al(r2)))
     return PDR_EINVAL;
   const int tpb = (rows_per_batch + 127) / 128;
-  const dim3 grid(static_cast<unsigned>(B) * tpb);
   hipStream_t st = pdr::as_stream(stream);
   const bool kpow2 = (K & (K - 1)) == 0 && K <= 32;
   const bool has_s = s1 != nullptr || s2 != nullptr;
+  pdr::GatherTwin tw{idx0, Yd, wrow0, ldyd, 0, wmul};
+  long nblocks = static_cast<long>(B) * tpb;
+  if (idx0) {
+    // twin blocks: the per-query rows (rows_per_batch / K per cloud) behind the main tiles
+    const int mq = rows_per_batch / K;
+    if (!Yd || !wrow0 || !partial || has_s || ldyd % 4 || ldyd < c4 || !al(Yd) ||
+        partial_tpb < tpb + (mq + 127) / 128)
+      return PDR_EINVAL;
+    tw.n_main = static_cast<int>(nblocks);
+    nblocks += static_cast<long>(B) * ((mq + 127) / 128);
+  }
+  if (nblocks >= (1L << 31)) return PDR_EINVAL;
+  const dim3 grid(static_cast<unsigned>(nblocks));
 #define PDR_GA_K(LPR, KP, HS)                                                                          \
   hipLaunchKernelGGL((gather_add_kernel<LPR, KP, HS>), grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
                      counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0, ycol0, \
-                     ycol0 + y4, tile_valid, partial_tpb)
+                     ycol0 + y4, tile_valid, partial_tpb, tw)
 #define PDR_GA(LPR)                                       \
   do {                                                    \
     if (kpow2 && has_s) PDR_GA_K(LPR, true, true);        \
@@ -615,6 +647,21 @@ extern "C" int pdr_gather_add_tiles(const float* U, int ldu, int n_src, const fl
   if (!tile_valid || partial_tpb < (rows_per_batch + 127) / 128) return PDR_EINVAL;
   return gather_add_impl(U, ldu, n_src, V, V0, ldv, idx, counts, s1, r1, s2, r2, B, rows_per_batch, K, Cout, Y, ldy,
                          partial, relu_col0, ycol0, ycols, tile_valid, partial_tpb, stream);
+}
+
+// pdr_gather_add_tiles + the block's per-QUERY rows in the same launch (round 5: was a second, K = 1 pdr_gather_add on
+// the first neighbours followed by pdr_weighted_moments): Yd (B m, ldyd) <- U[b, idx0[q]] + V[q] (empty ball: V0[q]),
+// every column; partial row b partial_tpb + tpb + j <- wmul x the moments of the rows q >= wrow0[b] of the cloud's
+// j-th group of 128 queries (m = rows_per_batch / K queries per cloud).  Ball form only (no s1 / s2).
+extern "C" int pdr_gather_add_tiles_twin(const float* U, int ldu, int n_src, const float* V, const float* V0,
+                                         int ldv, const int* idx, const int* counts, int B, int rows_per_batch, int K,
+                                         int Cout, float* Y, int ldy, float* partial, int relu_col0, int ycol0,
+                                         int ycols, const unsigned char* tile_valid, int partial_tpb, const int* idx0,
+                                         float* Yd, int ldyd, const int* wrow0, float wmul, pdr_stream_t stream) {
+  if (!tile_valid || !idx0 || rows_per_batch <= 0 || K <= 0 || rows_per_batch % K != 0) return PDR_EINVAL;
+  return gather_add_impl(U, ldu, n_src, V, V0, ldv, idx, counts, nullptr, nullptr, nullptr, nullptr, B, rows_per_batch,
+                         K, Cout, Y, ldy, partial, relu_col0, ycol0, ycols, tile_valid, partial_tpb, stream, idx0, Yd,
+                         ldyd, wrow0, wmul);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -746,6 +793,175 @@ extern "C" int pdr_dedup_plan(const int* idx, const int* counts, int B, int m, i
                      qpt, idx0, row_w, tile_valid);
   hipLaunchKernelGGL(dedup_compact_kernel, dim3(1), dim3(1024), 0, pdr::as_stream(stream), tile_valid,
                      static_cast<int>(ntiles), tile_list, n_tiles);
+  return pdr::check_launch();
+}
+
+// ---- sort + gathers + plan in ONE launch (round 5) ------------------------------------------------------------------
+// pdr_dedup_sort, the three pdr_gather_rows of the sorted index rows / counts / query coordinates and the two kernels
+// of pdr_dedup_plan were six dependent launches behind every ball query of the x_t branch -- at the head of a step they
+// sit between the first ball query and the first block (0.13 -> 0.38 ms in profiles/r4_timeline_markers.json).  With
+// the queries SORTED a cloud's valid tiles are simply its first nv = ceil(real / (128 / K)) tiles, so the whole plan is
+// a count + a stable partition per cloud: one 1024-thread workgroup per cloud does all of it.
+//   (1) real neighbourhoods (count > 1) of clouds 0 .. b -> this cloud's nv and the offset of its tiles in the list
+//       (every workgroup recounts its predecessors: B m int loads, L2 hits -- no inter-workgroup communication);
+//   (2) the stable partition of pdr_dedup_sort (perm / inv / perm_rows);
+//   (3) rows gathered into that order: index rows (K ints = 16-byte pieces), counts, coordinates, first neighbours,
+//       weights (K behind the cloud's valid tiles, else 0);
+//   (4) tile flags, the ascending tile list, per-cloud [nv | first weighted query], the probe counters.
+constexpr int kMaxPrepareClouds = 1024;
+
+__global__ __launch_bounds__(1024) void dedup_prepare_kernel(
+    const int* __restrict__ idx, const int* __restrict__ counts, const float* __restrict__ xyz, int m, int K, int nB,
+    int* __restrict__ perm, int* __restrict__ inv, int* __restrict__ perm_rows, int* __restrict__ idx_s,
+    int* __restrict__ counts_s, float* __restrict__ xyz_s, int* __restrict__ idx0, float* __restrict__ row_w,
+    unsigned char* __restrict__ tile_valid, int* __restrict__ tile_list, int* __restrict__ n_tiles,
+    int* __restrict__ nvalid, int* __restrict__ probe_acc) {
+  __shared__ int nreal_s[kMaxPrepareClouds];
+  __shared__ int wtot[16];
+  __shared__ int base_s, prefix_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int qpt = 128 / K, tpb = m / qpt;
+  for (int i = tid; i <= b; i += 1024) nreal_s[i] = 0;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  // (1) (loads of different clouds are independent: the compiler keeps several in flight)
+  for (int bb = 0; bb <= b; ++bb) {
+    const int* cb = counts + static_cast<long>(bb) * m;
+    int c = 0;
+    for (int i = tid; i < m; i += 1024) c += cb[i] > 1 ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0 && c) atomicAdd(&nreal_s[bb], c);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int p = 0;
+    for (int bb = 0; bb < b; ++bb) p += (nreal_s[bb] + qpt - 1) / qpt;
+    prefix_s = p;
+  }
+  const int nv = (nreal_s[b] + qpt - 1) / qpt;       // valid tiles of this cloud: its first nv
+  const int q0 = nv * qpt;                            // first query of the skipped tiles
+  // (2) stable partition: real neighbourhoods first
+  const int* cb = counts + static_cast<long>(b) * m;
+  int* pb = perm + static_cast<long>(b) * m;
+  int* ib = inv + static_cast<long>(b) * m;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+      const int i = i0 + tid;
+      const bool take = i < m && ((cb[i] > 1) == (pass == 0));
+      const unsigned long long bal = __ballot(take);
+      const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wtot[wave] = __builtin_popcountll(bal);
+      __syncthreads();
+      int woff = 0, tot = 0;
+      for (int w = 0; w < 16; ++w) {
+        woff += w < wave ? wtot[w] : 0;
+        tot += wtot[w];
+      }
+      const int base = base_s;
+      if (take) {
+        const int j = base + woff + before;
+        pb[j] = i;
+        ib[i] = j;
+        if (perm_rows) perm_rows[static_cast<long>(b) * m + j] = b * m + i;
+      }
+      __syncthreads();
+      if (tid == 0) base_s = base + tot;
+      __syncthreads();
+    }
+  }
+  // (the workgroup's own perm writes are visible to it behind the barrier above)
+  // (3) per-query rows in sorted order
+  for (int j = tid; j < m; j += 1024) {
+    const int src = pb[j];
+    const long qs = static_cast<long>(b) * m + src, qd = static_cast<long>(b) * m + j;
+    counts_s[qd] = cb[src];
+    idx0[qd] = idx[qs * K];
+    row_w[qd] = j >= q0 ? static_cast<float>(K) : 0.0f;
+    if (xyz) {
+      xyz_s[qd * 3 + 0] = xyz[qs * 3 + 0];
+      xyz_s[qd * 3 + 1] = xyz[qs * 3 + 1];
+      xyz_s[qd * 3 + 2] = xyz[qs * 3 + 2];
+    }
+  }
+  const int k4 = K / 4;                               // 16-byte pieces per index row (K in {8, 16, 32})
+  for (int e = tid; e < m * k4; e += 1024) {
+    const int j = e / k4, part = e - j * k4;
+    const int src = pb[j];
+    const int4 v = *reinterpret_cast<const int4*>(idx + (static_cast<long>(b) * m + src) * K + 4 * part);
+    *reinterpret_cast<int4*>(idx_s + (static_cast<long>(b) * m + j) * K + 4 * part) = v;
+  }
+  // (4) tiles
+  const int prefix = prefix_s;
+  for (int t = tid; t < tpb; t += 1024) {
+    tile_valid[static_cast<long>(b) * tpb + t] = t < nv ? 1 : 0;
+    if (t < nv) tile_list[prefix + t] = b * tpb + t;
+  }
+  if (tid == 0) {
+    nvalid[b] = nv;
+    nvalid[nB + b] = q0;
+    if (b == nB - 1) *n_tiles = prefix + nv;
+    if (probe_acc) {
+      atomicAdd(&probe_acc[0], nv);
+      atomicAdd(&probe_acc[1], tpb);
+    }
+  }
+}
+
+// The same count without the plan (the step with every neighbourhood evaluated carries it so that the sampler can tell
+// when the deduplicated step would be the faster one again): probe_acc[0] += tiles a plan would walk, [1] += tiles.
+__global__ __launch_bounds__(256) void dedup_probe_kernel(const int* __restrict__ counts, int m, int K,
+                                                          int* __restrict__ probe_acc) {
+  __shared__ int tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  const int* cb = counts + static_cast<long>(blockIdx.x) * m;
+  int c = 0;
+  for (int i = threadIdx.x; i < m; i += 256) c += cb[i] > 1 ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&tot, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int qpt = 128 / K;
+    atomicAdd(&probe_acc[0], (tot + qpt - 1) / qpt);
+    atomicAdd(&probe_acc[1], m / qpt);
+  }
+}
+
+// idx (B, m, K) int32 / counts (B, m) of a ball query, xyz (B, m, 3) query coordinates (may be NULL) -> everything a
+// grouped block needs to evaluate its one-point neighbourhoods once, in ONE launch (= pdr_dedup_sort + pdr_gather_rows
+// of idx / counts / xyz + pdr_dedup_plan on the sorted arrays, same values):
+//   perm, inv, perm_rows (B, m): the stable partition (real neighbourhoods first) as in pdr_dedup_sort;
+//   idx_s (B, m, K), counts_s (B, m), xyz_s (B, m, 3): the inputs in that order;
+//   idx0, row_w (B, m), tile_valid (B m K / 128), tile_list, n_tiles: as pdr_dedup_plan on the sorted arrays;
+//   nvalid (2 B ints): [b] = valid tiles of cloud b (its FIRST nv tiles), [B + b] = nv * (128 / K) = the first query of
+//   its skipped tiles (pdr_layer_in_t.wrow0 of the per-query launches);
+//   probe_acc (NULL or 2 ints): [0] += sum_b nv, [1] += B m K / 128.
+extern "C" int pdr_dedup_prepare(const int* idx, const int* counts, const float* xyz, int B, int m, int K, int* perm,
+                                 int* inv, int* perm_rows, int* idx_s, int* counts_s, float* xyz_s, int* idx0,
+                                 float* row_w, unsigned char* tile_valid, int* tile_list, int* n_tiles, int* nvalid,
+                                 int* probe_acc, pdr_stream_t stream) {
+  if (!idx || !counts || !perm || !inv || !idx_s || !counts_s || (xyz && !xyz_s) || !idx0 || !row_w || !tile_valid ||
+      !tile_list || !n_tiles || !nvalid || B < 0 || m <= 0)
+    return PDR_EINVAL;
+  if (!(K == 8 || K == 16 || K == 32) || (static_cast<long>(m) * K) % 128 != 0) return PDR_EINVAL;
+  if (static_cast<long>(B) * m * K >= (1L << 31)) return PDR_EINVAL;
+  if (B > kMaxPrepareClouds) return PDR_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(idx_s)) % 16 != 0) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  hipLaunchKernelGGL(dedup_prepare_kernel, dim3(B), dim3(1024), 0, pdr::as_stream(stream), idx, counts, xyz, m, K, B,
+                     perm, inv, perm_rows, idx_s, counts_s, xyz_s, idx0, row_w, tile_valid, tile_list, n_tiles, nvalid,
+                     probe_acc);
+  return pdr::check_launch();
+}
+
+extern "C" int pdr_dedup_probe(const int* counts, int B, int m, int K, int* probe_acc, pdr_stream_t stream) {
+  if (!counts || !probe_acc || B < 0 || m <= 0) return PDR_EINVAL;
+  if (!(K == 8 || K == 16 || K == 32) || (static_cast<long>(m) * K) % 128 != 0) return PDR_EINVAL;
+  if (B == 0) return PDR_OK;
+  hipLaunchKernelGGL(dedup_probe_kernel, dim3(B), dim3(256), 0, pdr::as_stream(stream), counts, m, K, probe_acc);
   return pdr::check_launch();
 }
 

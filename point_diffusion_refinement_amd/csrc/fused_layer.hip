@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     // s_waitcnt vmcnt(0) that drains the previous store (stores count in vmcnt on gfx950).
     int il_e = il;
     asm volatile("" : "+v"(il_e));
-    const bool rows_full = nvalid == TM;   // uniform
+    // weighted statistics (in.wrow0, see pdr_layer_in_t): rows below wrow0[b] do not count, the rest x wmul
+    const int wlo = in.wrow0 ? min(max(in.wrow0[b] - tb * TM, 0), TM) : 0;   // uniform
+    const bool rows_full = nvalid == TM && wlo == 0;   // uniform
     if constexpr (POOL) {
       // a 32-row MFMA tile holds 32 / K whole queries (K in {8, 16, 32}); for a fixed column a
       // query's K rows sit in registers {r : (r >> 2) / (K / 8) == g} of both lane halves
@@ -465,9 +467,11 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
               const float y = acc[i][j][r] + bv;
               if (rl < nvalid) {
                 ybase[rl * ldy] = y;
-                const float f = relu_stat ? fmaxf(y, 0.0f) : y;
-                s1 += f;
-                s2 = __builtin_fmaf(f, f, s2);
+                if (rl >= wlo) {
+                  const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+                  s1 += f;
+                  s2 = __builtin_fmaf(f, f, s2);
+                }
               }
             }
           }
@@ -476,6 +480,10 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
       if (partial) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
+        if (in.wrow0) {
+          s1 *= in.wmul;
+          s2 *= in.wmul;
+        }
         if (hi == 0) {
           red[wr][cl][0] = s1;
           red[wr][cl][1] = s2;
@@ -491,7 +499,9 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
           s1 += red[w][tid][0];
           s2 += red[w][tid][1];
         }
-        float* o = partial + (static_cast<long>(tile) * Cout + n0 + tid) * 2;
+        // (row b partial_tpb + tb of `partial`, as the wave-specialised kernels: partial_tpb = 0 -> tiles per batch)
+        const long prow = static_cast<long>(b) * (in.partial_tpb > 0 ? in.partial_tpb : tpb) + tb;
+        float* o = partial + (prow * Cout + n0 + tid) * 2;
         o[0] = s1;
         o[1] = s2;
       }
@@ -541,6 +551,11 @@ struct FoldPart {
   const float* partial;   // first of `C` columns inside rows of `ldp` columns
   int ldp, tiles_per_batch, C;
   double mult;
+  // a tile SUBSET produced these rows (round 5): of the first tpb_main rows of batch element b only the first
+  // nvalid[b] were written (sorted queries: a cloud's valid tiles are its first ones) -- the others are skipped, not
+  // read as zeros (nobody zeroes them any more); rows >= tpb_main (the per-query rows' moments) always count
+  const int* nvalid;
+  int tpb_main;
 };
 
 __global__ __launch_bounds__(1024) void gn_fold_wide_kernel(FoldPart p0, FoldPart p1, int C, int Cn, int G,
@@ -568,13 +583,15 @@ __global__ __launch_bounds__(1024) void gn_fold_wide_kernel(FoldPart p0, FoldPar
       double s1 = 0.0, s2 = 0.0;
       if (c < p.C) {
         const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + c) * 2;
+        const int nv = p.nvalid ? p.nvalid[b] : p.tpb_main;
         for (int t = sl; t < p.tiles_per_batch; t += nsl * 8) {
           float2 v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const int tt = t + nsl * u;
-            v[u] = tt < p.tiles_per_batch ? *reinterpret_cast<const float2*>(q + static_cast<long>(tt) * p.ldp * 2)
-                                          : make_float2(0.0f, 0.0f);
+            v[u] = (tt < p.tiles_per_batch && !(tt >= nv && tt < p.tpb_main))
+                       ? *reinterpret_cast<const float2*>(q + static_cast<long>(tt) * p.ldp * 2)
+                       : make_float2(0.0f, 0.0f);
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
@@ -661,6 +678,9 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(FoldPart p0, FoldPart p1, 
     mult = p.mult;
     const long stride = static_cast<long>(p.ldp) * 2;
     const float* q = p.partial + (static_cast<long>(b) * p.tiles_per_batch * p.ldp + col) * 2;
+    // (loaded beside the partial rows, consumed behind them: no extra dependent round trip)
+    const int nv = p.nvalid ? p.nvalid[b] : p.tpb_main;
+    const int tpb_main = p.tpb_main;
     for (int t = sl; t < p.tiles_per_batch; t += 8 * U) {
       // U loads in flight: unconditional, from a clamped tile (t itself is valid), zeroed afterwards -- a load
       // under `tt < tiles` compiles to a branch with its own vmcnt(0), i.e. U dependent round trips per trip
@@ -672,7 +692,8 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(FoldPart p0, FoldPart p1, 
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool ok = t + 8 * u < p.tiles_per_batch;
+        const int tt = t + 8 * u;
+        const bool ok = tt < p.tiles_per_batch && !(tt >= nv && tt < tpb_main);   // (skipped tiles hold garbage)
         s1 += ok ? v[u].x : 0.0f;
         s2 += ok ? v[u].y : 0.0f;
       }
@@ -950,6 +971,9 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
     if (in->rows_per_batch % d != 0 || (in->rows_per_batch > t.tm && t.tm % d != 0)) return PDR_EUNSUPPORTED;
   }
   const long nb = P / in->rows_per_batch;
+  // rows of `partial` per batch element: at least its tiles (a smaller stride would fold tiles of two batch elements
+  // into one row); weighted statistics come with a weight
+  if (in->partial_tpb > 0 && in->partial_tpb < (in->rows_per_batch + t.tm - 1) / t.tm) return PDR_EINVAL;
   pl->t = t;
   pl->ntiles = nb * ((in->rows_per_batch + t.tm - 1) / t.tm);
   pl->ncol = (Cout + t.tn - 1) / t.tn;
@@ -1111,6 +1135,8 @@ extern "C" int pdr_fused_layer_f16x3(const pdr_layer_in_t* in, long P, int Cin, 
   if (prc != PDR_OK) return prc;
   if (P == 0) return PDR_OK;
   if (!pl.ws || (pl.t.id != 4 && pl.t.id != 5 && pl.t.id != 8)) return PDR_EUNSUPPORTED;
+  // a tile subset is a list of 128-row tile numbers with its length on the device (as pdr_fused_layer)
+  if (in->tile_list && (!in->n_tiles || pl.t.tm != 128)) return PDR_EUNSUPPORTED;
   int nch = 0;
   for (int s = 0; s < in->n_seg; ++s) nch += (in->seg[s].C + 31) / 32;
   if (nch != nchunks) return PDR_EINVAL;   // the image was packed for another segment structure
@@ -1200,7 +1226,8 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
       pdr::launch_fused_layer_ws(t.id, false, false, *in, Cin, Wt, ldw, bias, D, nullptr, 0, nullptr, D, nt, ncol, s,
                                  false, &pa))
     return pdr::check_launch();
-  if (in->tile_list || in->out_rows) return PDR_EUNSUPPORTED;   // tile subsets / row maps: wave-specialised kernels only
+  // tile subsets / row maps / patched rows: wave-specialised kernels only
+  if (in->tile_list || in->out_rows || in->patch_values) return PDR_EUNSUPPORTED;
 #define PDR_LAUNCH_P(RT, CT, WR, WC, KC)                                                              \
   hipLaunchKernelGGL((fused_layer_kernel<RT, CT, WR, WC, KC, false, true, false, true>), grid, dim3(256), \
                      0, s, *in, Cin, Wt, ldw, bias, D, static_cast<float*>(nullptr), 0,                   \
@@ -1236,14 +1263,18 @@ extern "C" int pdr_gn_reduce(const float* partial, int ldp, int B, int tiles_per
 extern "C" int pdr_gn_fold(const float* part0, int ldp0, int tpb0, int C0, double mult0,
                            const float* part1, int ldp1, int tpb1, int C1, double mult1, int B, int Cn,
                            int G, double n, float eps, const float* gamma, const float* beta,
-                           float* scale, float* shift, pdr_stream_t stream) {
+                           float* scale, float* shift, const int* nvalid0, int tpb_main0, const int* nvalid1,
+                           int tpb_main1, pdr_stream_t stream) {
   if (!part0 || C0 <= 0 || tpb0 <= 0 || ldp0 < C0 || B <= 0 || G <= 0 || !scale || !shift)
     return PDR_EINVAL;
   if (part1 && (C1 <= 0 || tpb1 <= 0 || ldp1 < C1)) return PDR_EINVAL;
+  if ((nvalid0 && (tpb_main0 <= 0 || tpb_main0 > tpb0)) || (nvalid1 && (!part1 || tpb_main1 <= 0 || tpb_main1 > tpb1)))
+    return PDR_EINVAL;
   const int C = C0 + (part1 ? C1 : 0);
   if (Cn < 0 || Cn > C || (Cn > 0 && (Cn % G != 0 || !gamma || !beta))) return PDR_EINVAL;
-  FoldPart p0{part0, ldp0, tpb0, C0, mult0};
-  FoldPart p1{part1, ldp1, tpb1, part1 ? C1 : 0, mult1};
+  // (without a subset: nv = tpb_main = 0 -- the range [nv, tpb_main) of skipped rows is empty)
+  FoldPart p0{part0, ldp0, tpb0, C0, mult0, nvalid0, nvalid0 ? tpb_main0 : 0};
+  FoldPart p1{part1, ldp1, tpb1, part1 ? C1 : 0, mult1, nvalid1, nvalid1 ? tpb_main1 : 0};
   static const bool small_form = [] {
     const char* e = getenv("PDR_GN_FOLD_SMALL");
     return !(e && e[0] == '0');

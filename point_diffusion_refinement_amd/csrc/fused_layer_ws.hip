@@ -164,6 +164,37 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   const int my_tiles = tile_limit > tile_first ? (tile_limit - tile_first + tile_step - 1) / tile_step : 0;
   // (XCD-local order with more workgroups per XCD than local tiles: nothing to do -- and the producers' first fetch
   // below must not run on a tile that does not exist)
+  if constexpr (POOL) {
+    // ---- pooled rows of the queries in SKIPPED tiles (in.patch_values; round 5: was the pdr_patch_rows launch behind
+    // this one): a one-point neighbourhood's pooled row is its activated value row.  Inputs of this launch only (the
+    // per-query value rows, the folded value GroupNorm), rows that no tile of this launch writes: done first, by all
+    // eight waves, grid-strided over the queries -- also by the workgroups that own no tile.
+    if (in.patch_values) {
+      constexpr int TN4p = TN / 4;
+      constexpr int QP = 512 / TN4p;                       // queries per pass of this workgroup
+      const int Kp = pool.K;
+      const long nq = static_cast<long>(n_row_tiles) * TM / Kp;
+      const int qpb = rpb / Kp;
+      const int c = n0 + 4 * (tid % TN4p);
+      const float lo = pool.v_relu ? 0.0f : -__builtin_inff();
+      if (tid < QP * TN4p && c < Cout) {
+        for (long q = static_cast<long>(blockIdx.x) * QP + tid / TN4p; q < nq; q += static_cast<long>(gridDim.x) * QP) {
+          if (in.patch_w[q] > 0.0f) {
+            const long bq = q / qpb;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in.patch_values + q * in.patch_ld + c);
+            f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (pool.vscale) sc = *reinterpret_cast<const f32x4*>(pool.vscale + bq * Cout + c);
+            if (pool.vshift) sh = *reinterpret_cast<const f32x4*>(pool.vshift + bq * Cout + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = vmax(__builtin_fmaf(v[j], sc[j], sh[j]), lo);
+            const long orow = in.out_rows ? static_cast<long>(in.out_rows[q]) : q;
+            *reinterpret_cast<f32x4*>(pool.out + orow * pool.ldo + c) = o;
+          }
+        }
+      }
+    }
+  }
   if (my_tiles == 0) return;
 #ifdef PDR_LAB_TRACE
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
@@ -686,7 +717,10 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
       const int tile = b * ptpb + tb;          // index of the tile's partial row
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
       const int nvalid = min(TM, rpb - tb * TM);
-      const bool rows_full = nvalid == TM;   // uniform
+      // (weighted statistics -- in.wrow0, the per-query launches of a deduplicated block -- take the per-row path below:
+      // a few small launches per step; the full-tile path of every other launch stays as it is)
+      constexpr bool WSTAT = GATH == 0;   // (the per-query rows are materialised: the gathered forms stay as they were)
+      const bool rows_full = nvalid == TM && !(WSTAT && in.wrow0);   // uniform
       // opaque copies: keep the per-row store offsets from being hoisted out of the chunk loop
       // (64 live 64-bit addresses would spill)
       int il_e = il, hi_e = hi, lane_e = lane;
@@ -874,7 +908,10 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
             store_tile(M2(), std::false_type());   // unaligned output: scalar stores, general statistics
           }
         } else {
-          // ---- partial row tile (last tile of a batch element): per-row predicates
+          // ---- partial row tile (last tile of a batch element) or weighted statistics: per-row predicates.
+          // Weighted: only the rows r >= wrow0[b] of the batch element count, times wmul (pdr_layer_in_t.wrow0).
+          int wlo = 0;                                             // uniform
+          if constexpr (WSTAT) wlo = in.wrow0 ? in.wrow0[b] - tb * TM : 0;
           const bool relu_stat = col >= relu_col0;
           float* ybase = Y + row0 * ldy + col;
           // (rare path: one row at a time keeps its register footprint small)
@@ -889,12 +926,20 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
                   float y = acc[i][j][r];
                   if (ob) y += ob[((row0 + rl) >> osh) * in.oadd_ld];
                   ybase[rl * ldy] = y;
-                  const float f = relu_stat ? fmaxf(y, 0.0f) : y;
-                  s1 += f;
-                  s2 = __builtin_fmaf(f, f, s2);
+                  if (rl >= wlo) {
+                    const float f = relu_stat ? fmaxf(y, 0.0f) : y;
+                    s1 += f;
+                    s2 = __builtin_fmaf(f, f, s2);
+                  }
                 }
                 __builtin_amdgcn_sched_barrier(0);
               }
+            }
+          }
+          if constexpr (WSTAT) {
+            if (in.wrow0) {                  // uniform: every counted row stands for wmul copies
+              s1 *= in.wmul;
+              s2 *= in.wmul;
             }
           }
         }
@@ -968,6 +1013,7 @@ namespace pdr {
 // Whether tile variant `id` (pick_tile() of fused_layer.hip) has a wave-specialised instantiation for this input.
 bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin) {
   if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
+  if (in.wrow0 && gath) return false;   // weighted statistics: the plain-source instantiations (and the uniform kernel)
   if (id == 3 || id == 6 || id > 8) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;

@@ -41,6 +41,16 @@ struct PoolArgs {
   int ldv, ldo, K, v_relu;
 };
 
+// Twin blocks of pdr_gather_add_tiles_twin (fused_gather.hip): the per-query rows of a deduplicated block's first conv
+// and their weighted moments, computed by extra workgroups of the launch that walks the tile subset.
+struct GatherTwin {
+  const int* idx0;     // (B, m) first neighbour of every query
+  float* Y;            // (B m, ldy): the first conv of the per-query rows, every column
+  const int* wrow0;    // (B): first query of cloud b whose row counts in the moments
+  int ldy, n_main;     // n_main: workgroups of the main tiles (0: no twin blocks)
+  float wmul;          // weight of the counted rows (K)
+};
+
 // fused_layer_ws.hip: wave-specialised layer kernel; false = no instantiation for this tile variant
 bool fused_layer_ws_supported(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin);
 bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(float* __restrict__ x
                                                            const float* __restrict__ ts_table,
                                                            float* __restrict__ ts_out,
                                                            unsigned long long* __restrict__ rng, int* __restrict__ ticket,
-                                                           long total) {
+                                                           long total, int* __restrict__ probe_acc,
+                                                           int* __restrict__ probe_out) {
   const long quad = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   const long long t = *t_ptr;
   // t < 0 is a replay past the last step: x is left alone (the tables are not indexed at -1), the ticket still runs
@@ -136,6 +137,14 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(float* __restrict__ x
       *t_ptr = tn;
       if (ts_out && tn >= 0) *ts_out = ts_table ? ts_table[tn] : static_cast<float>(tn);
       if (rng) rng[1] += 1ull;
+      if (probe_acc) {
+        // this step's neighbourhood probe (accumulated by the geometry launches long before this kernel) -> the slot
+        // the host polls; reset for the next step
+        probe_out[0] = probe_acc[0];
+        probe_out[1] = probe_acc[1];
+        probe_acc[0] = 0;
+        probe_acc[1] = 0;
+      }
     }
   }
 }
@@ -172,9 +181,9 @@ extern "C" int pdr_reverse_update(float* x, const float* eps, int ld_eps, const 
 extern "C" int pdr_reverse_step(float* x, const float* eps, int ld_eps, const float* z, const float* tab_a,
                                 const float* tab_b, const float* tab_c, long long* t_dev, const float* ts_table,
                                 float* ts_out, unsigned long long* rng_state, int* ticket, long npoints, int mode,
-                                pdr_stream_t stream) {
+                                int* probe_acc, int* probe_out, pdr_stream_t stream) {
   if (!x || !eps || !tab_a || !tab_b || !tab_c || !t_dev || !ticket || npoints < 0 || ld_eps < 3 ||
-      (mode != 0 && mode != 1))
+      (mode != 0 && mode != 1) || ((probe_acc == nullptr) != (probe_out == nullptr)))
     return PDR_EINVAL;
   if (npoints == 0) return PDR_OK;
   const long total = npoints * 3;
@@ -182,9 +191,9 @@ extern "C" int pdr_reverse_step(float* x, const float* eps, int ld_eps, const fl
   hipStream_t s = pdr::as_stream(stream);
   if (mode == 0)
     hipLaunchKernelGGL(reverse_step_kernel<0>, grid, dim3(256), 0, s, x, eps, ld_eps, z, tab_a, tab_b, tab_c, t_dev,
-                       ts_table, ts_out, rng_state, ticket, total);
+                       ts_table, ts_out, rng_state, ticket, total, probe_acc, probe_out);
   else
     hipLaunchKernelGGL(reverse_step_kernel<1>, grid, dim3(256), 0, s, x, eps, ld_eps, z, tab_a, tab_b, tab_c, t_dev,
-                       ts_table, ts_out, rng_state, ticket, total);
+                       ts_table, ts_out, rng_state, ticket, total, probe_acc, probe_out);
   return pdr::check_launch();
 }

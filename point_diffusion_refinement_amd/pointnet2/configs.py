@@ -70,3 +70,44 @@ def synthetic_batch(B, N=2048, M=3072, seed=0, device=None):
     if device is not None:
         x, cond, label = x.to(device), cond.to(device), label.to(device)
     return x, cond, label
+
+
+def synthetic_surface_batch(B, N=2048, M=3072, seed=0, device=None):
+    """Synthetic inputs shaped like a real completion job (bench.py's `trajectory` leg, the dense-regime tests): x_0 =
+    N points on a torus inside [-0.5, 0.5]^3 (major radius 0.33, minor radius 0.08 - 0.16, own random rotation per cloud --
+    the scale of the MVP shapes, whose neighbourhood radii the architecture's 0.1 ... 1.6 were chosen for), condition =
+    its partial view (the M / 2 points nearest to a random viewpoint direction) mirrored about z with the +-1 flag
+    channel (data_utils/mirror_partial.py:21-33), labels ~ U{0..15}.  With `q_sample` below this gives the marginal
+    x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps a trained network's trajectory follows (reference util.py:280-282)
+    without a checkpoint.  CPU generator => the same values on every machine."""
+    import math
+    import torch
+    g = torch.Generator().manual_seed(1000 + seed)
+    u = torch.rand(B, N, generator=g) * 2 * math.pi
+    v = torch.rand(B, N, generator=g) * 2 * math.pi
+    R = 0.33
+    r = 0.08 + 0.08 * torch.rand(B, 1, generator=g)
+    p = torch.stack([(R + r * torch.cos(v)) * torch.cos(u), (R + r * torch.cos(v)) * torch.sin(u), r * torch.sin(v)], 2)
+    # a random rotation per cloud (QR of a Gaussian matrix)
+    q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+    x0 = torch.bmm(p, q).contiguous()
+    view = torch.nn.functional.normalize(torch.randn(B, 1, 3, generator=g), dim=2)
+    order = (x0 * view).sum(2).argsort(dim=1, descending=True)[:, :M // 2]
+    half = torch.gather(x0, 1, order[:, :, None].expand(-1, -1, 3))
+    mirrored = half * torch.tensor([1.0, 1.0, -1.0])
+    cond = torch.cat([torch.cat([half, torch.ones(B, M // 2, 1)], 2),
+                      torch.cat([mirrored, -torch.ones(B, M // 2, 1)], 2)], 1).contiguous()
+    label = torch.randint(0, 16, (B,), generator=g)
+    if device is not None:
+        x0, cond, label = x0.to(device), cond.to(device), label.to(device)
+    return x0, cond, label
+
+
+def q_sample(x0, t, diffusion_hyperparams, seed=0):
+    """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps (reference util.py:280-282, the training marginal), eps from a CPU
+    generator keyed by (seed, t)."""
+    import torch
+    ab = diffusion_hyperparams["Alpha_bar"][int(t)].item()
+    g = torch.Generator().manual_seed(7919 * int(seed) + int(t))
+    eps = torch.randn(x0.shape, generator=g).to(x0.device)
+    return (ab ** 0.5) * x0 + ((1.0 - ab) ** 0.5) * eps

@@ -74,6 +74,12 @@ GATHER_RES_KNN = True
 LEVEL_EVENTS = True
 # Step-embedding chain as three pdr_embed_linear launches instead of ~12 torch / hipBLASLt ones (False: torch chain)
 NATIVE_EMBED = True
+# ... and, inside a sampler's loop, not even those: the chain depends on t only, so the samplers evaluate it for all T
+# step values of their schedule once (FusedCloudConditionNet.build_step_table) and a step looks its row up
+# (pdr_embed_select, one launch).  Round 3 measured this bit-identical and dropped it because the chain was hidden
+# behind the first ball query; with one-point neighbourhoods evaluated once it ended at 0.28 ms of a 6.4-ms step
+# (profiles/r4_timeline_markers.json).
+STEP_TABLE = True
 # The global PointNet of a new batch (models/pnet.py) through the fused layer kernels (False: the torch module ->
 # MIOpen convolutions, what rounds 1-3 did)
 FUSE_GLOBAL_PNET = True
@@ -90,11 +96,23 @@ LAB_SKIP_FOLD = False
 # decoder halves hoisted, 64 -> 6.43 / 6.44, 16 -> 6.30: even the 16-query blocks, whose launches do next to nothing).
 DEDUP = True
 DEDUP_MIN_QUERIES = 16
-# ... on the block's queries SORTED per cloud, real neighbourhoods first (pdr_dedup_sort): a tile is walked when ANY of
-# its 4 queries has a real neighbourhood, so unsorted 14 % such queries keep 45 % of the tiles; sorted, 14 %.  The
-# block's per-query inputs (index rows, counts, coordinates, query features) are gathered in that order, its output
-# is gathered back.
-DEDUP_SORT = True
+# ... on the block's queries SORTED per cloud, real neighbourhoods first: a tile is walked when ANY of its 4 queries has a
+# real neighbourhood, so unsorted 14 % such queries keep 45 % of the tiles; sorted, 14 %.  The block's per-query inputs
+# (index rows, counts, coordinates, query features) are gathered in that order, its pooled rows are written back to
+# their original places.  (Round 4 kept the unsorted form as a variant; round 5 builds on the sorted structure -- a
+# cloud's valid tiles are its FIRST ones, the per-query rows that count are its LAST ones -- and dropped it.)
+#
+# Round 5: the launches the deduplicated step had added, taken out again (each with its round-4 form as a cross-check):
+# sort + three row gathers + two plan kernels behind every ball query as ONE launch (pdr_dedup_prepare) ...
+FUSED_PLAN = True
+# ... the moments of the per-query rows computed by the per-query launches themselves (pdr_layer_in_t.wrow0 / wmul,
+# pdr_gather_add_tiles_twin) and a fold that skips a cloud's invalid tile range (pdr_gn_fold nvalid) instead of a
+# pdr_weighted_moments launch + zero fills behind every layer; the K = 1 first-neighbour gather_add rides in the
+# launch that walks the tile subset ...
+TWIN_STATS = True
+# ... and the pooled rows of the skipped tiles' queries written by the pooled launch (pdr_layer_in_t.patch_values)
+# instead of a pdr_patch_rows launch behind it.
+FUSED_PATCH = True
 # The query-independent half of the DECODER's feature-transfer blocks (first-conv statistics, shared MLP, value conv: it
 # needs coordinates, the static condition features and the step embeddings only) on the geometry stream once that
 # stream is done with the geometry (1.4 ms into the step), beside the encoder; the decoder then only runs the query /
@@ -166,6 +184,9 @@ class Act:
         self.oadd = None               # (tensor (rows, ld), div): output-side per-query add
         self.dd = None                 # Dedup plan of the block: the launch walks its tile subset
         self.twin = None               # the same activation over the block's per-QUERY rows (first neighbour only)
+        self.wrow0, self.wmul = None, 0.0   # a twin's weighted statistics: rows >= wrow0[b] count, x wmul
+        self.ptpb = 0                  # partial rows per cloud of the launch in flight (run_layer sets it)
+        self.patch = None              # pooled launch: (per-query value rows, row weights) of the skipped tiles
 
     _SHARED = ("scale", "shift", "add", "add_ld", "pre_relu", "post_relu", "ss_ld")
 
@@ -198,15 +219,39 @@ class Act:
                 li.gs1, li.gs2 = self.gs1.data_ptr(), self.gs2.data_ptr()
         if self.dd is not None:
             li.tile_list, li.n_tiles = self.dd.tile_list.data_ptr(), self.dd.n_tiles.data_ptr()
-            li.partial_tpb = self.dd.ptpb
+            li.partial_tpb = self.ptpb or self.dd.ptpb
+        elif self.ptpb:
+            li.partial_tpb = self.ptpb
+        if self.wrow0 is not None:
+            li.wrow0, li.wmul = self.wrow0.data_ptr(), self.wmul
+        if self.patch is not None:
+            Vd, w = self.patch
+            li.patch_values, li.patch_ld, li.patch_w = Vd.data_ptr(), Vd.shape[1], w.data_ptr()
         return li
 
 
-class Dedup:
-    """Plan of one grouped block's per-neighbour launches (pdr_dedup_plan): which 128-row tiles hold a real
-    neighbourhood, the weights / first neighbours of the per-query chain that stands in for the others."""
+# One-point neighbourhoods are evaluated once only while BOTH hold: the module constant above (tests / lab A-B) and the
+# switch of the network whose forward is in flight (FusedCloudConditionNet.dedup: the sampler captures the step both
+# ways and picks per step, reverse_sampler.py).
+_NET_DEDUP = [True]
+# probe counters of the forward in flight (int32[2] device tensor or None): [0] += tiles a plan walks, [1] += tiles
+_PROBE = [None]
 
-    def __init__(self, idx, counts, B, m, K):
+
+def _dedup_on():
+    return DEDUP and _NET_DEDUP[0]
+
+
+def _probe_ptr():
+    return _PROBE[0].data_ptr() if _PROBE[0] is not None else None
+
+
+class Dedup:
+    """Plan of one grouped block's per-neighbour launches on its SORTED queries: which 128-row tiles hold a real
+    neighbourhood (a cloud's first nvalid[b]), the weights / first neighbours of the per-query chain that stands in for
+    the others (a cloud's queries from wrow0[b] on)."""
+
+    def __init__(self, idx, counts, B, m, K, prepared=None):
         dev = idx.device
         self.B, self.m, self.K = B, m, K
         self.tpb, self.tpbd = m * K // 128, (m + 127) // 128
@@ -217,34 +262,71 @@ class Dedup:
         self.tile_valid = torch.empty((nt,), dtype=torch.uint8, device=dev)
         self.tile_list = torch.empty((nt,), dtype=torch.int32, device=dev)
         self.n_tiles = torch.empty((1,), dtype=torch.int32, device=dev)
+        self.nvalid = None                                     # (2, B) int32: [valid tiles | first weighted query]
+        if prepared is not None:
+            prepared(self)                                     # pdr_dedup_prepare fills everything (SortedQueries)
+            return
         _lib.check(_lib.load().pdr_dedup_plan(idx.data_ptr(), counts.data_ptr(), B, m, K, self.idx0.data_ptr(),
                                               self.row_w.data_ptr(), self.tile_valid.data_ptr(),
                                               self.tile_list.data_ptr(), self.n_tiles.data_ptr(), _stream()),
                    "dedup_plan")
+        # (the round-4 form, a cross-check variant: what pdr_dedup_prepare also returns, in a few torch launches)
+        nv = self.tile_valid.view(B, self.tpb).sum(1, dtype=torch.int32)
+        self.nvalid = torch.stack([nv, nv * (128 // K)]).contiguous()
+        if _PROBE[0] is not None:
+            _PROBE[0][0:1] += self.n_tiles
+            _PROBE[0][1:2] += nt
+
+    @property
+    def wrow0(self):
+        return self.nvalid[1]
 
     def moments(self, Yd, C, relu_col0, partial):
-        """Weighted moments of the per-query rows behind the tile subset's, zeros for the skipped tiles."""
+        """Weighted moments of the per-query rows behind the tile subset's, zeros for the skipped tiles (the round-4
+        form: TWIN_STATS = False)."""
         _lib.check(_lib.load().pdr_weighted_moments(Yd.data_ptr(), Yd.shape[1], self.B, self.m, C, relu_col0,
                                                     self.row_w.data_ptr(), partial.data_ptr(), self.ptpb, self.tpb,
                                                     self.tile_valid.data_ptr(), _stream()), "weighted_moments")
 
 
 class SortedQueries:
-    """A grouped block's queries in the order it evaluates them under DEDUP_SORT (pdr_dedup_sort of the ball counts):
-    permutation, inverse, and the ball query's outputs / the query coordinates gathered into that order."""
+    """A grouped block's queries in the order it evaluates them: the stable partition of the ball counts (real
+    neighbourhoods first), its inverse, the ball query's outputs / the query coordinates gathered into that order, and
+    the Dedup plan of the sorted arrays (`plan`).  One pdr_dedup_prepare launch (FUSED_PLAN; six launches before)."""
 
     def __init__(self, idx, counts, new_xyz):
         B, m, K = idx.shape
         dev = idx.device
+        lib = _lib.load()
         self.perm = torch.empty((B, m), dtype=torch.int32, device=dev)
         self.inv = torch.empty((B, m), dtype=torch.int32, device=dev)
         self.perm_rows = torch.empty((B, m), dtype=torch.int32, device=dev)     # b m + perm: rows of a (B m)-row tensor
-        _lib.check(_lib.load().pdr_dedup_sort(counts.data_ptr(), B, m, self.perm.data_ptr(), self.inv.data_ptr(),
-                                              self.perm_rows.data_ptr(), _stream()), "dedup_sort")
+        self.plan = None
+        if FUSED_PLAN and K in (8, 16, 32) and (m * K) % 128 == 0 and B <= 1024:
+            new_xyz = new_xyz.contiguous()
+            self.idx = torch.empty_like(idx)
+            self.counts = torch.empty_like(counts)
+            self.xyz = torch.empty_like(new_xyz)
+            nvalid = torch.empty((2, B), dtype=torch.int32, device=dev)
+
+            def prepared(dd):
+                _lib.check(lib.pdr_dedup_prepare(
+                    idx.data_ptr(), counts.data_ptr(), new_xyz.data_ptr(), B, m, K, self.perm.data_ptr(),
+                    self.inv.data_ptr(), self.perm_rows.data_ptr(), self.idx.data_ptr(), self.counts.data_ptr(),
+                    self.xyz.data_ptr(), dd.idx0.data_ptr(), dd.row_w.data_ptr(), dd.tile_valid.data_ptr(),
+                    dd.tile_list.data_ptr(), dd.n_tiles.data_ptr(), nvalid.data_ptr(), _probe_ptr(), _stream()),
+                    "dedup_prepare")
+                dd.nvalid = nvalid
+            self.plan = Dedup(self.idx, self.counts, B, m, K, prepared=prepared)
+            return
+        _lib.check(lib.pdr_dedup_sort(counts.data_ptr(), B, m, self.perm.data_ptr(), self.inv.data_ptr(),
+                                      self.perm_rows.data_ptr(), _stream()), "dedup_sort")
         # (rows of 32-bit words moved as they are: the row gather does no arithmetic)
         self.idx = gather_rows(idx.view(torch.float32), self.perm).view(torch.int32)
         self.counts = gather_rows(counts.view(B, m, 1).view(torch.float32), self.perm).view(torch.int32).view(B, m)
         self.xyz = gather_rows(new_xyz.contiguous(), self.perm)
+        if K in (8, 16, 32) and (m * K) % 128 == 0:
+            self.plan = Dedup(self.idx, self.counts, B, m, K)
 
 
 def act_from(Y, C, P, B, rpb, **kw):
@@ -253,8 +335,16 @@ def act_from(Y, C, P, B, rpb, **kw):
     dd = getattr(Y, "_dd", None)
     if dd is not None:
         a.dd = dd
-        a.twin = Act([(Y._twin, 0, C, Y._twin.shape[1], 1)], dd.B * dd.m, B, dd.m, **kw)
+        a.twin = _twin_act([(Y._twin, 0, C, Y._twin.shape[1], 1)], dd, B, **kw)
     return a
+
+
+def _twin_act(segs, dd, B, **kw):
+    """Act over a deduplicated block's per-QUERY rows; with TWIN_STATS its launch weights its own statistics."""
+    tw = Act(segs, dd.B * dd.m, B, dd.m, **kw)
+    if TWIN_STATS:
+        tw.wrow0, tw.wmul = dd.wrow0, float(dd.K)
+    return tw
 
 
 class FirstOut:
@@ -298,7 +388,7 @@ class FirstOut:
                 if len(act.segs) != 1 or len(act.segs[0]) <= 5:
                     raise NotImplementedError("deduplicated block: one gathered source per layer")
                 _, col0, C = act.segs[0][:3]
-                tw = Act([(Yd, col0, C, Yd.shape[1], 1)], dd.B * dd.m, act.B, dd.m)
+                tw = _twin_act([(Yd, col0, C, Yd.shape[1], 1)], dd, act.B)
                 for k in Act._SHARED:
                     object.__setattr__(tw, k, getattr(act, k))
                 act.dd, act.twin = dd, tw
@@ -456,7 +546,7 @@ def pack_f16x3(Wt, Cout, seg_widths, TN=128):
     return img.view(torch.int16).reshape(-1), len(chunks)
 
 
-def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, relu_col0):
+def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial_ptr, relu_col0):
     """Try the f16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel)."""
     if _PRECISION[0] != "split_f16" or conv.Cin < SPLIT_MIN_CIN:
         return False
@@ -470,8 +560,7 @@ def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, relu_col0):
         cache[key] = pack_f16x3(conv.Wt, conv.Cout, key[:-1], TN)
     img, nch = cache[key]
     rc = lib.pdr_fused_layer_f16x3(ctypes.byref(li), act.P, conv.Cin, img.data_ptr(), nch, conv.bias.data_ptr(),
-                                    conv.Cout, y_ptr, ldy, partial.data_ptr() if partial is not None else None,
-                                    relu_col0, _stream())
+                                    conv.Cout, y_ptr, ldy, partial_ptr, relu_col0, _stream())
     if rc == _lib.PDR_EUNSUPPORTED:
         return False
     _lib.check(rc, "fused_layer_f16x3")
@@ -505,12 +594,14 @@ class FoldReq:
         return self.norm.fold(parts, B, self.C, self.n)
 
 
-def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fold=None):
+def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fold=None, stats_into=None):
     """Y (P, Cout) = prologue(act) . Wt + bias; returns (Y, partial or None, tiles_per_batch).
     extra_rows: zero rows appended to Y (the zero row of a gathered table); out = (tensor, col0): write into
     columns [col0, col0 + ldy') of an existing (P, ld) tensor instead of allocating.
     fold: a FoldReq -- returns (Y, partial, tiles_per_batch, (scale, shift)): the GroupNorm fold (pdr_gn_fold) of this
-    layer's statistics is launched right behind it."""
+    layer's statistics is launched right behind it.
+    stats_into = (partial, first row, rows per cloud): the statistics go to rows [b rows_per_cloud + first row + tile] of
+    an existing partial tensor (the per-query launch of a deduplicated layer, behind the tile subset's rows)."""
     lib = _lib.load()
     assert act.C == conv.Cin, (act.C, conv.Cin)
     ldy = _ldy(conv.Cout)
@@ -525,20 +616,29 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
     tm = lib.pdr_fused_layer_tile_rows(act.rpb, conv.Cout)
     tpb = (act.rpb + tm - 1) // tm
     dd = act.dd
+    stats = stats or fold is not None
+    twin_stats = dd is not None and act.twin is not None and stats and TWIN_STATS and act.twin.wrow0 is not None
     if dd is not None:
         assert tm == 128 and tpb == dd.tpb and out is None and not extra_rows, (tm, tpb, dd.tpb)
-        tpb = dd.ptpb                   # rows of `partial` per cloud: the tile subset's + the per-query rows'
-    partial = None
-    stats = stats or fold is not None
-    if stats:
+        # rows of `partial` per cloud: the tile subset's + the per-query rows' (TWIN_STATS: one per tile of the
+        # per-query launch, whatever tile height that launch picks; else pdr_weighted_moments' groups of 128 rows)
+        tmd = lib.pdr_fused_layer_tile_rows(dd.m, conv.Cout)
+        tpb = dd.tpb + ((dd.m + tmd - 1) // tmd if twin_stats else dd.tpbd)
+    partial = partial_ptr = None
+    act.ptpb = 0
+    if stats_into is not None:
+        partial, row0, act.ptpb = stats_into
+        partial_ptr = _ptr(partial, row0 * conv.Cout * 2)
+    elif stats:
         partial = torch.empty((act.B * tpb, conv.Cout, 2), dtype=torch.float32, device=Y.device)
+        partial_ptr = partial.data_ptr()
+        act.ptpb = tpb if dd is not None else 0
     li = act.struct()
     rc0 = conv.Cout if relu_col0 is None else relu_col0
-    done = _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial, rc0)
+    done = _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial_ptr, rc0)
     if not done:
         rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
-                                 conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
-                                 partial.data_ptr() if stats else None, rc0, _stream())
+                                 conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, partial_ptr, rc0, _stream())
         if rc == _lib.PDR_EUNSUPPORTED and act.gs1 is not None and act.first is not None:
             # a kNN-form gathered source reached a tile shape without a wave-specialised kernel: materialise the
             # columns it reads (one pdr_gather_add window per segment) and run the layer on plain sources
@@ -551,15 +651,22 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
             plain_act.ss_ld, plain_act.oadd = act.ss_ld, act.oadd
             li = plain_act.struct()
             rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
-                                     conv.bias.data_ptr(), conv.Cout, y_ptr, ldy,
-                                     partial.data_ptr() if stats else None, rc0, _stream())
+                                     conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, partial_ptr, rc0, _stream())
         _lib.check(rc, "fused_layer")
     if dd is not None and act.twin is not None:
         # the same layer over the per-query rows (first neighbour of every query): its rows stand for the K copies
         # in the skipped tiles -- moments weighted by K there, 0 elsewhere
-        Yd = run_layer(act.twin, conv, relu_col0=relu_col0)[0]
-        if stats:
-            dd.moments(Yd, conv.Cout, rc0, partial)
+        if twin_stats:
+            # ... computed by that launch itself (pdr_layer_in_t.wrow0 / wmul) into the rows behind the tile subset's;
+            # the fold skips the rows of the tiles the subset skipped (Norm.fold reads `_sub`)
+            Yd = run_layer(act.twin, conv, relu_col0=relu_col0, stats_into=(partial, dd.tpb, tpb))[0]
+            partial._sub = (dd.nvalid[0], dd.tpb)
+        else:
+            saved, act.twin.wrow0 = act.twin.wrow0, None
+            Yd = run_layer(act.twin, conv, relu_col0=relu_col0)[0]
+            act.twin.wrow0 = saved
+            if stats:
+                dd.moments(Yd, conv.Cout, rc0, partial)
         Y._twin, Y._dd = Yd, dd
     if fold is None:
         return Y, partial, tpb
@@ -567,6 +674,9 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
 
 
 def materialize(act):
+    # (a deduplicated activation holds uninitialised rows in its skipped tiles: only the layer kernels, which walk the
+    # tile subset, may read it)
+    assert act.dd is None, "materialize() of a deduplicated block's activation"
     lib = _lib.load()
     out = torch.empty((act.P, act.C), dtype=torch.float32, device=act.segs[0][0].device)
     li = act.struct()
@@ -601,10 +711,15 @@ class Norm:
             (pb, cb, nb, tb, mb) = parts[1]
             second = (_ptr(pb, 2 * cb), pb.shape[1], tb, nb, float(mb))
         else:
-            second = (None, 0, 0, 0, 1.0)
+            pb, second = None, (None, 0, 0, 0, 1.0)
+
+        def sub(t):
+            # statistics of a tile SUBSET (run_layer / SplitFirstConv tag them): (valid tiles per cloud, main tiles)
+            v = getattr(t, "_sub", None) if t is not None else None
+            return (v[0].data_ptr(), v[1]) if v is not None else (None, 0)
         _lib.check(lib.pdr_gn_fold(_ptr(pa, 2 * ca), pa.shape[1], ta, na, float(ma), *second, B, self.Cn, self.G,
                                    float(n), float(self.eps), self.gamma.data_ptr(), self.beta.data_ptr(),
-                                   scale.data_ptr(), shift.data_ptr(), _stream()), "gn_fold")
+                                   scale.data_ptr(), shift.data_ptr(), *sub(pa), *sub(pb), _stream()), "gn_fold")
         if LAB_SKIP_FOLD:
             self._lab_fold[(B, C, n)] = (scale, shift)
         return scale, shift
@@ -837,9 +952,14 @@ class FusedAttention:
         cptr = counts.data_ptr() if counts is not None else None
         vsp, vtp = (vs.data_ptr(), vt.data_ptr()) if vs is not None else (None, None)
 
+        # queries of the skipped tiles: one unmasked neighbour, i.e. the pooled row is its activated value row --
+        # written by the pooled launch itself (FUSED_PATCH; a pdr_patch_rows launch behind it before)
+        patched = dd is not None and FUSED_PATCH and fused_pool and V.shape[1] % 4 == 0
+        if patched:
+            score_in.patch = (V._twin, dd.row_w)
+
         def patch():
-            # queries of the skipped tiles: one unmasked neighbour, i.e. the pooled row is its activated value row
-            if dd is not None:
+            if dd is not None and not patched:
                 Vd = V._twin
                 _lib.check(lib.pdr_patch_rows(Vd.data_ptr(), Vd.shape[1], vsp, vtp, int(self.v_relu),
                                               dd.row_w.data_ptr(), B, npoint, self.D, out.data_ptr(), self.D,
@@ -1002,16 +1122,25 @@ class SplitFirstConv:
                     B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols)
             if dd is None:
                 _lib.check(lib.pdr_gather_add(*args, _stream()), "gather_add")
-                return
-            _lib.check(lib.pdr_gather_add_tiles(*args, dd.tile_valid.data_ptr(), ptpb, _stream()), "gather_add_tiles")
+                return None
             # the first conv of every query's FIRST neighbour, materialised (B m rows): the per-query chain's input
             Yd = torch.empty((B * m, ld), dtype=torch.float32, device=U.device)
+            if TWIN_STATS:
+                # ... written, with its weighted moments, by extra workgroups of the launch that walks the tile subset
+                _lib.check(lib.pdr_gather_add_tiles_twin(
+                    U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, idx32.data_ptr(), cptr,
+                    B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols,
+                    dd.tile_valid.data_ptr(), ptpb, dd.idx0.data_ptr(), Yd.data_ptr(), ld, dd.wrow0.data_ptr(),
+                    float(K), _stream()), "gather_add_tiles_twin")
+                partial._sub = (dd.nvalid[0], dd.tpb)
+                return Yd
+            _lib.check(lib.pdr_gather_add_tiles(*args, dd.tile_valid.data_ptr(), ptpb, _stream()), "gather_add_tiles")
             _lib.check(lib.pdr_gather_add(
                 U.data_ptr(), ld, n, V2.data_ptr(), _ptr(V2, ld) if has_v0 else None, ldv, dd.idx0.data_ptr(), cptr,
                 None, None, None, None, B, m, 1, self.Cout, Yd.data_ptr(), ld, None, relu_col0, 0, -1, _stream()),
                 "gather_add")
             dd.moments(Yd, self.Cout, relu_col0, partial)
-            dd.Yd = Yd
+            return Yd
 
         # (a thunk: the fold is launched by whoever consumes it, i.e. on the stream that runs the rest of the MLP)
         folded = (lambda: fold.launch(partial, ptpb, B)) if fold is not None else None
@@ -1024,13 +1153,13 @@ class SplitFirstConv:
         Yres = None
         if res is not None and res[1] <= GATHER_RES and (s1 is None or GATHER_RES_KNN):
             res = None                        # consumers gather the residual window like any other
-            gather_add(None, ld, 0, -1)
+            Yd = gather_add(None, ld, 0, -1)
         elif res is not None and res[0] % 4 == 0:
             Yres = torch.empty((B * rpb, _pad4(res[1])), dtype=torch.float32, device=U.device)
-            gather_add(Yres.data_ptr(), Yres.shape[1], res[0], res[1])
+            Yd = gather_add(Yres.data_ptr(), Yres.shape[1], res[0], res[1])
         else:
             res = None
-            gather_add(None, ld, 0, -1)
+            Yd = gather_add(None, ld, 0, -1)
         def materialise(col0, C):
             """Columns [col0, col0 + C) of the conv output as a tensor (fallback of consumers that cannot gather)."""
             assert col0 % 4 == 0
@@ -1047,7 +1176,7 @@ class SplitFirstConv:
                          res_cols=res[1] if res else 0, s1=s1, s2=s2, r1=self.r1 if s1 is not None else None,
                          r2=self.r2 if s1 is not None else None, materialise=materialise)
         if dd is not None:
-            first.dd, first.deg = dd, dd.Yd
+            first.dd, first.deg = dd, Yd
         return first, partial, ptpb, folded
 
 
@@ -1144,37 +1273,41 @@ class FusedGroupedBlock:
         return self.__dict__[key]
 
     def _plan(self, idx, counts, B, m, K):
-        """The Dedup plan of this block's neighbourhoods, or None when the block runs whole.  A plan made earlier for
-        the same index tensor (plan_ahead: on the geometry stream, shared by the encoder / decoder feature-transfer
-        blocks of a level) is reused."""
+        """The Dedup plan of this block's (sorted) neighbourhoods, or None when the block runs whole.  A plan made
+        earlier for the same index tensor (plan_ahead: on the geometry stream, shared by the encoder / decoder
+        feature-transfer blocks of a level) is reused."""
         if not self._eligible(idx, m, K):
             return None
-        dd = getattr(idx, "_plan", None)
-        if dd is None:
-            dd = idx._plan = Dedup(idx, counts, B, m, K)
-        return dd
+        # (only ever the plan of SORTED queries: the weighted statistics and the fold's skipped range rely on a cloud's
+        # valid tiles being its first ones -- an index tensor that did not pass plan_ahead runs whole)
+        return getattr(idx, "_plan", None)
 
-    def _eligible(self, idx, m, K):
-        return (DEDUP and self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
+    def _shape_ok(self, idx, m, K):
+        """This block COULD evaluate its one-point neighbourhoods once (whatever the switches say)."""
+        return (self.dedup and USE_SPLIT_FIRST and USE_VIRTUAL_FIRST and SPLIT_QUERY_CONV and
                 K in (8, 16, 32) and m >= DEDUP_MIN_QUERIES and (m * K) % 128 == 0 and idx.dtype == torch.int32 and
                 self._ws_kernels_on() and self._tiles_128(m * K))
 
+    def _eligible(self, idx, m, K):
+        return _dedup_on() and self._shape_ok(idx, m, K)
+
     def _sorted(self, idx):
         """The SortedQueries made for this index tensor, when this block evaluates its queries in that order."""
-        return getattr(idx, "_sorted", None) if (DEDUP and DEDUP_SORT and self.dedup) else None
+        return getattr(idx, "_sorted", None) if (_dedup_on() and self.dedup) else None
 
     def plan_ahead(self, neigh, new_xyz):
-        """On the CURRENT stream (the one that produced `neigh`), ahead of the block: the query order and the plan."""
+        """On the CURRENT stream (the one that produced `neigh`), ahead of the block: the query order and the plan --
+        or, in a forward that evaluates every neighbourhood, only the probe count of what a plan would walk."""
         idx, counts = neigh
         B, m, K = idx.shape
         if self._eligible(idx, m, K):
-            if DEDUP_SORT and getattr(idx, "_sorted", None) is None:
+            if getattr(idx, "_sorted", None) is None:
                 idx._sorted = SortedQueries(idx, counts, new_xyz)
-            sq = self._sorted(idx)
-            if sq is not None:
-                self._plan(sq.idx, sq.counts, B, m, K)
-            else:
-                self._plan(idx, counts, B, m, K)
+            sq = idx._sorted
+            sq.idx._plan = sq.plan                         # (the plan of the sorted arrays, made with them)
+        elif _PROBE[0] is not None and self._shape_ok(idx, m, K) and not getattr(idx, "_probed", False):
+            _lib.check(_lib.load().pdr_dedup_probe(counts.data_ptr(), B, m, K, _probe_ptr(), _stream()), "dedup_probe")
+            idx._probed = True
         return neigh
 
     def side_tables(self, neigh, new_xyz, has_v0):
@@ -1339,6 +1472,7 @@ class FusedKnnFP:
 
 def act_colmax(act):
     """(B, C) = max over every batch element's rows of the lazily-activated `act` (pdr_act_colmax)."""
+    assert act.dd is None, "act_colmax() of a deduplicated block's activation"
     out = torch.empty((act.B, act.C), dtype=torch.float32, device=act.segs[0][0].device)
     li = act.struct()
     _lib.check(_lib.load().pdr_act_colmax(ctypes.byref(li), act.P, act.C, out.data_ptr(), _stream()), "act_colmax")
@@ -1471,6 +1605,16 @@ class FusedCloudConditionNet:
         self.return_strided_eps = False
         self.two_streams = True       # the two halves of every block on two streams (False: profiling tools that want
         self._label_key = None        # every kernel alone on the chip)
+        # One-point neighbourhoods evaluated once (DEDUP) in THIS network's forwards.  The samplers capture the step both
+        # ways and switch per step (reverse_sampler.py); the refinement forward, whose input is a finished surface, turns
+        # it off (generation.refine_completion).
+        self.dedup = True
+        # probe: int32[2] device counters a forward adds to -- [0] tiles the deduplicated step walks / would walk, [1]
+        # tiles of its deduplicable blocks (pdr_dedup_prepare / pdr_dedup_probe); None = no probe launches
+        self.probe = None
+        # (table (T, W) of every block's fc(t_emb) rows for all step values of a schedule, int64 device step counter):
+        # set by a sampler (build_step_table); the step's embedding chain is then ONE row lookup (pdr_embed_select)
+        self.step_table = None
 
     def _side_stream(self):
         if self._side is None:
@@ -1559,8 +1703,8 @@ class FusedCloudConditionNet:
                 if use_retained_condition_feature and label is not None:
                     self._refresh_class_embedding(label)
                 return out
-        saved = _PRECISION[0]
-        _PRECISION[0] = self.precision
+        saved = _PRECISION[0], _NET_DEDUP[0], _PROBE[0]
+        _PRECISION[0], _NET_DEDUP[0], _PROBE[0] = self.precision, bool(self.dedup), self.probe
         saved_par = _PAR["stream"]
         _PAR["stream"] = self._aux_stream() if self.two_streams else None
         try:
@@ -1569,7 +1713,7 @@ class FusedCloudConditionNet:
                 self._condition_branch(condition)
             return self._forward_cached(pointcloud, condition, ts, label)
         finally:
-            _PRECISION[0] = saved
+            _PRECISION[0], _NET_DEDUP[0], _PROBE[0] = saved
             _PAR["stream"] = saved_par
             if not use_retained_condition_feature:
                 self.reset_cond_features()
@@ -1580,7 +1724,9 @@ class FusedCloudConditionNet:
         class-embedding GEMM when the label tensor changed (identity + version), both IN PLACE."""
         net, hp, bank = self.net, self.net.hparams, self.bank
         if ts is not None and hp['include_t']:
-            if not (NATIVE_EMBED and ts.is_cuda and "t" in bank.W and self._embed_linear_chain(ts)):
+            if STEP_TABLE and self.step_table is not None and self._embed_select(ts.shape[0]):
+                pass
+            elif not (NATIVE_EMBED and ts.is_cuda and "t" in bank.W and self._embed_linear_chain(ts)):
                 t_emb = net.activation(net.fc_t1(calc_t_emb(ts, hp['t_dim'])))
                 t_emb = net.activation(net.fc_t2(t_emb))
                 bank.evaluate_kind("t", t_emb)
@@ -1597,6 +1743,39 @@ class FusedCloudConditionNet:
             self.bank.evaluate_kind("c2", self.net.class_emb(label), static=True)
         # (the key holds the tensor itself: while it is referenced here its address cannot be recycled)
         self._label_key = (label, label._version)
+
+    def build_step_table(self, ts_values):
+        """Every block's fc(t_emb) rows for ALL the step values of a schedule ((T,) float32 tensor: entry i = the
+        network time input while a sampler's device step counter reads i), through the same three pdr_embed_linear
+        launches as a step's chain with T rows instead of B -- the chain depends on t only, a row's arithmetic does not
+        depend on the rows beside it, so a looked-up row holds the bits the per-step chain would produce.  None when
+        the shapes are outside the kernels' contract."""
+        bank = self.bank
+        if not (STEP_TABLE and NATIVE_EMBED and self.net.hparams['include_t'] and "t" in bank.W and ts_values.is_cuda):
+            return None
+        saved = bank.out.get("t")
+        ok = self._embed_linear_chain(ts_values.float().contiguous())
+        table = bank.out.get("t") if ok else None
+        if saved is not None:
+            bank.out["t"] = saved
+        elif "t" in bank.out:
+            del bank.out["t"]
+        if table is None or table.shape[1] % 4 != 0:
+            return None
+        return table
+
+    def _embed_select(self, B):
+        """bank.out["t"] (B, W) <- row `step counter` of the step table (pdr_embed_select): the whole embedding chain
+        of a step as one lookup launch."""
+        table, t_dev = self.step_table
+        out = torch.empty((B, table.shape[1]), dtype=torch.float32, device=table.device)
+        rc = _lib.load().pdr_embed_select(table.data_ptr(), table.shape[1], table.shape[0], t_dev.data_ptr(), B,
+                                          table.shape[1], out.data_ptr(), out.shape[1], _stream())
+        if rc == _lib.PDR_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "embed_select")
+        self.bank.out["t"] = out
+        return True
 
     def _embed_linear_chain(self, ts):
         """calc_t_emb -> fc_t1 -> swish -> fc_t2 -> swish -> every block's fc (pointnet2_with_pcld_condition.py

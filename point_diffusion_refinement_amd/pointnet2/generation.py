@@ -66,7 +66,18 @@ def refine_completion(refine_net, generated, condition, label, output_scale_fact
     (B,N,3) coarse -> (B, N f, 3)."""
     from .models.point_upsample_module import point_upsample
     refine_net.reset_cond_features()
-    displacement = refine_net(generated, condition, ts=None, label=label)
+    # the fused network evaluates a ball that holds one point once (fused_network.DEDUP) -- the rule on the noisy x_t of
+    # a reverse process, the exception HERE: the refinement input is a finished surface, every ball is full, the
+    # per-query chain would be pure overhead (bench.py `trajectory.refinement_forward` times both).  One eager forward
+    # per batch: no probe, the switch is simply off.
+    saved = getattr(refine_net, "dedup", None)
+    if saved is not None:
+        refine_net.dedup = False
+    try:
+        displacement = refine_net(generated, condition, ts=None, label=label)
+    finally:
+        if saved is not None:
+            refine_net.dedup = saved
     if point_upsample_factor > 1:
         refined, _ = point_upsample(generated, displacement, point_upsample_factor,
                                     include_displacement_center_to_final_output, output_scale_factor)

@@ -18,16 +18,37 @@ is captured into a hipGraph once per batch shape and replayed T-1 times:
   * the first step of a batch (condition branch + global PointNet, results retained by
     the network) runs eagerly, as does graph capture itself.
 The arithmetic per step is the reference's, in the same order.
+
+Two captured forms of the step (round 5).  The fused network evaluates a neighbourhood that ball_query filled with K
+copies of one point ONCE (fused_network.DEDUP) -- the rule while x_t is noise, i.e. for most of a
+reverse process -- at the price of a per-query chain beside every per-neighbour launch; on a finished surface, where
+balls are full, that chain is pure overhead.  The sampler therefore captures the step BOTH ways (`once` and `whole`,
+each on first need) and picks per step on the host: every step counts, on the device, the tiles a deduplicated step
+walks / would walk (pdr_dedup_prepare / pdr_dedup_probe), the step's last kernel publishes the two counters into
+pinned host memory, and before launching step i the host waits for step i-2 (an event: the queue never runs dry, the
+GPU never waits) and reads them -- `once` while the walked share stays below WHOLE_ABOVE, `whole` above it.  Same
+results either way (the two forms differ by fp32 summation order of GroupNorm moments only).
 """
 import torch
 
 
 class GraphedReverseSampler:
-    def __init__(self, net, diffusion_hyperparams, noise='device', use_graph=True):
+    # neighbourhoods='adaptive': walked share (tiles walked / tiles of the deduplicable blocks) above which the step
+    # with every neighbourhood evaluated is replayed.  bench.py's `trajectory` leg times both forms over the share.
+    WHOLE_ABOVE = 0.55
+
+    def __init__(self, net, diffusion_hyperparams, noise='device', use_graph=True, neighbourhoods='adaptive'):
+        """neighbourhoods: 'adaptive' (default; see the module docstring), 'once' / 'whole' = one form for every step
+        (networks without the switch -- the layer-by-layer module -- have one form anyway)."""
         assert noise in ('cpu', 'device')
+        assert neighbourhoods in ('adaptive', 'once', 'whole')
         self.net = net
         self.noise = noise
         self.use_graph = use_graph
+        self.neighbourhoods = neighbourhoods if hasattr(net, "dedup") else 'once'
+        self._graphs = {}
+        self._mode = 'once'
+        self.mode_counts = {'once': 0, 'whole': 0}
         dh = diffusion_hyperparams
         self.T = int(dh["T"])
         self.device = next(net.parameters()).device
@@ -39,8 +60,17 @@ class GraphedReverseSampler:
         sig[0] = 0.0
         self.sigma = sig.to(self.device)
         self._sigma_raw = S.to(self.device)            # Sigma[step] of the restart option (sigma_0 not zeroed)
-        self._graph = None
         self._key = None
+        self._step_table = None                        # built on first use (needs the subclass's time table)
+
+    @property
+    def _graph(self):
+        """(tests / tools) the captured step in use."""
+        return self._graphs.get(self._mode)
+
+    def _network_times(self):
+        """(T,) network time inputs indexed by the device step counter: float(t) (DDPM); subclasses: their tau table."""
+        return torch.arange(self.T, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ one step
     NOISE_AT_LAST_STEP = False     # util.sampling draws no noise at t = 0
@@ -82,11 +112,14 @@ class GraphedReverseSampler:
         assert z is None or (z.is_contiguous() and z.device == x.device and z.dtype == torch.float32)
         tab = self._ts_table()
         with torch.cuda.device(x.device):
+            probe = getattr(self.net, "probe", None)
             _lib.check(_lib.load().pdr_reverse_step(
                 x.data_ptr(), eps.data_ptr(), eps.stride(1), None if z is None else z.data_ptr(), a.data_ptr(),
                 b.data_ptr(), c.data_ptr(), self._t.data_ptr(), None if tab is None else tab.data_ptr(),
                 self._ts.data_ptr(), self._rng.data_ptr() if device_noise else None, self._ticket.data_ptr(), B * N,
-                self.UPDATE_MODE, torch.cuda.current_stream(x.device).cuda_stream), "reverse_step")
+                self.UPDATE_MODE, None if probe is None else probe.data_ptr(),
+                None if probe is None else self._probe_host.data_ptr(),
+                torch.cuda.current_stream(x.device).cuda_stream), "reverse_step")
 
     def _ts_table(self):
         """Device table of network time inputs indexed by the step counter, or None = float(t) (DDPM)."""
@@ -104,14 +137,23 @@ class GraphedReverseSampler:
         saved_flag = getattr(self.net, "return_strided_eps", None)
         if strided:
             self.net.return_strided_eps = True         # fused network: hand over its 4-float output rows as a view
+        fused = hasattr(self.net, "dedup")
+        if fused:
+            saved_net = self.net.dedup, self.net.probe, self.net.step_table
+            self.net.dedup = self._mode == 'once'
+            # the probe counters travel only with the native step (its last kernel publishes and resets them)
+            self.net.probe = self._probe if (native and self.neighbourhoods == 'adaptive') else None
+            self.net.step_table = (self._table(), self._t) if native else None
         try:
             eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
+            if native:
+                self._step_native(eps)
+                return
         finally:
             if strided:
                 self.net.return_strided_eps = saved_flag
-        if native:
-            self._step_native(eps)
-            return
+            if fused:
+                self.net.dedup, self.net.probe, self.net.step_table = saved_net
         z = torch.randn_like(self._x) if self.noise == 'device' else self._z
         if keep_slice is not None:
             if self.UPDATE_MODE != 0:
@@ -129,7 +171,7 @@ class GraphedReverseSampler:
     def _prepare(self, size, condition, label):
         key = (tuple(size), tuple(condition.shape), None if label is None else tuple(label.shape))
         if self._key != key:
-            self._graph = None
+            self._graphs = {}
             self._key = key
             self._x = torch.empty(size, device=self.device)
             self._z = torch.empty(size, device=self.device)
@@ -139,15 +181,30 @@ class GraphedReverseSampler:
             self._ts = torch.zeros((1,), dtype=torch.float32, device=self.device)     # network time input of the step
             self._rng = torch.zeros((2,), dtype=torch.int64, device=self.device)      # Philox key, draw number
             self._ticket = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            # neighbourhood probe: device counters (the network's geometry launches add to them, the step's last kernel
+            # publishes and zeroes them) and their pinned, device-visible host copy
+            self._probe = torch.zeros((2,), dtype=torch.int32, device=self.device)
+            self._probe_host = torch.zeros((2,), dtype=torch.int32).pin_memory() if self.device.type == "cuda" \
+                else torch.zeros((2,), dtype=torch.int32)
+            self._events = []
         self._cond.copy_(condition)
         if label is not None:
             self._label.copy_(label)
 
+    def _table(self):
+        """The network's step-embedding table for this sampler's schedule (built once; None: per-step chain)."""
+        if self._step_table is None:
+            build = getattr(self.net, "build_step_table", None)
+            tab = build(self._network_times()) if build is not None else None
+            self._step_table = (tab,)
+        return self._step_table[0]
+
     def _capture(self):
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
-        state = (self._x, self._t, self._ts, self._rng)
+        state = (self._x, self._t, self._ts, self._rng, self._probe)
         saved = [v.clone() for v in state]
+        self._table()                                  # (built outside the capture, if it was not yet)
 
         def restore():
             for v, w in zip(state, saved):
@@ -160,9 +217,12 @@ class GraphedReverseSampler:
         with torch.cuda.graph(g):
             self._step()
         restore()
-        self._graph = g
-        # the graph has baked in the addresses of the retained condition features
-        self._static_cache = self._cache_tensors()
+        first = not self._graphs
+        self._graphs[self._mode] = g
+        # the graph has baked in the addresses of the retained condition features (the second form is captured on the
+        # same tensors: by then the network already points at them)
+        if first:
+            self._static_cache = self._cache_tensors()
 
     _CACHE_ATTRS = ("l_uvw", "encoder_cond_features", "decoder_cond_features")
 
@@ -208,8 +268,16 @@ class GraphedReverseSampler:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             self._rng.copy_(torch.tensor([seed, 0], dtype=torch.int64))
         self.remaining = t0 + 1
+        self._mode = 'whole' if self.neighbourhoods == 'whole' else 'once'
+        self._probe.zero_()
+        self._events = []
         self._advance_eager(keep_slice)                # first step: condition branch runs and is retained
-        if self._graph is not None:
+        if self.neighbourhoods == 'adaptive' and self.device.type == "cuda":
+            # once per batch: the first step's probe decides the form of the second (a restart from a stored x^step
+            # begins on a surface); later steps read the probe of two steps before without waiting for the device
+            torch.cuda.current_stream(self.device).synchronize()
+            self._pick_mode()
+        if self._graphs:
             self._adopt_cache()
         if hasattr(self.net, "sync_condition"):
             self.net.sync_condition()                  # fused network: refresh its channel-last copies in place
@@ -226,19 +294,37 @@ class GraphedReverseSampler:
         self._step(keep_slice)
         self.remaining -= 1
 
+    def _pick_mode(self):
+        """Form of the next step from the newest published probe (host memory; no device wait)."""
+        walked, total = int(self._probe_host[0]), int(self._probe_host[1])
+        if total > 0:
+            self._mode = 'whole' if walked > self.WHOLE_ABOVE * total else 'once'
+        self.walked_share = walked / total if total > 0 else None
+
     @torch.no_grad()
     def advance(self, n=1):
         """Run n more reverse steps (graph replay)."""
+        adaptive = self.neighbourhoods == 'adaptive'
         for _ in range(n):
             assert self.remaining > 0, "reverse process already finished"
+            if adaptive and self.device.type == "cuda":
+                # wait for the step before the previous one (keeps two steps queued), then read what it published
+                if len(self._events) >= 2:
+                    self._events.pop(0).synchronize()
+                    self._pick_mode()
             if not self.use_graph:
                 self._advance_eager()
-                continue
-            if self._graph is None:
-                self._capture()
-            self._draw_cpu_noise()
-            self._graph.replay()
-            self.remaining -= 1
+            else:
+                if self._mode not in self._graphs:
+                    self._capture()
+                self._draw_cpu_noise()
+                self._graphs[self._mode].replay()
+                self.remaining -= 1
+            self.mode_counts[self._mode] += 1
+            if adaptive and self.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._events.append(ev)
 
     @torch.no_grad()
     def finish(self):
@@ -293,9 +379,9 @@ class GraphedFastSampler(GraphedReverseSampler):
     NOISE_AT_LAST_STEP = True      # _ddim_update draws std_normal on every step, also when sigma = 0
 
     def __init__(self, net, diffusion_hyperparams, diffusion_config, length=50, sampling_method='var',
-                 schedule='quadratic', kappa=0.0, noise='device', use_graph=True):
+                 schedule='quadratic', kappa=0.0, noise='device', use_graph=True, neighbourhoods='adaptive'):
         from . import util_fastdpmv2 as F
-        super().__init__(net, diffusion_hyperparams, noise=noise, use_graph=use_graph)
+        super().__init__(net, diffusion_hyperparams, noise=noise, use_graph=use_graph, neighbourhoods=neighbourhoods)
         dh = diffusion_hyperparams
         assert sampling_method in ('var', 'step') and schedule in ('quadratic', 'linear') and 0.0 <= kappa <= 1.0
         if sampling_method == 'var':
@@ -334,6 +420,9 @@ class GraphedFastSampler(GraphedReverseSampler):
         return self.f_tau.index_select(0, t)
 
     def _ts_table(self):
+        return self.f_tau
+
+    def _network_times(self):
         return self.f_tau
 
     def _tables(self):

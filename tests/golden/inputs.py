@@ -62,3 +62,17 @@ def ddpm_inputs(B=1, N=2048, M=3072):
 def refine_coarse(B=1, N=2048):
     """Coarse completed cloud handed to the refinement network: U[-1,1]^3 (the range of completed MVP shapes)."""
     return (torch.rand(B, N, 3, generator=_gen(41)) * 2 - 1).contiguous()
+
+
+def dense_inputs(B=2):
+    """x_0 (B,2048,3) synthetic surfaces (tori in [-0.5, 0.5]^3), condition (B,3072,4) their mirrored partial views,
+    labels: the dense / mixed-ball regime of a reverse process' last steps (configs.synthetic_surface_batch, seed 7)."""
+    from point_diffusion_refinement_amd.pointnet2.configs import synthetic_surface_batch
+    return synthetic_surface_batch(B, seed=7)
+
+
+def dense_xt(x0, t):
+    """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps of the T = 1000 schedule (reference util.py:280-282), eps seeded by t."""
+    from point_diffusion_refinement_amd.pointnet2 import util
+    from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG, q_sample
+    return q_sample(x0, t, util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG), seed=7).contiguous()

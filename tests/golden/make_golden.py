@@ -182,6 +182,37 @@ def sampling_ddpm_b6():
     save("sampling_ddpm_b6.npz", out=out, xs=torch.stack(rec.xs))
 
 
+def dense_ddpm():
+    """The DENSE / MIXED-ball regime at full size (VERDICT r4 missing 3: every other full-size fixture draws x from
+    N(0,1) or U[-1,1]^3 -- at most one expected point per r = 0.1 ball).  Shipped DDPM architecture, B = 2, x_0 = synthetic
+    tori, condition = their mirrored partial views:
+      * forwards at x_t = q_sample(x_0, t): the first (retaining) call at t = 50, cached calls at t = 49 and t = 200 --
+        balls of 10-30 points at the fine levels, full (nsample = 32, query_ball_point's early exit,
+        ball_query_gpu.cu:27-44) at the coarse ones;
+      * `sampling` restarted from a precomputed x (util.py:217-222: use_a_precomputed_XT, step = 4, XT = x_0): four
+        network calls that END on the surface; the x handed to every call is stored."""
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    from util import calc_diffusion_hyperparams, sampling
+    from tests.parity import InputRecorder
+    x0, cond, label = I.dense_inputs(2)
+    net = fill_deterministic(PointNet2CloudCondition(R.load_config()['pointnet_config']), 31).eval()
+    one = torch.ones(2)
+    with torch.no_grad():
+        first = net(I.dense_xt(x0, 50), cond, ts=50 * one, label=label, use_retained_condition_feature=True)
+        c49 = net(I.dense_xt(x0, 49), cond, ts=49 * one, label=label, use_retained_condition_feature=True)
+        c200 = net(I.dense_xt(x0, 200), cond, ts=200 * one, label=label, use_retained_condition_feature=True)
+    net.reset_cond_features()
+    dh = calc_diffusion_hyperparams(1000, 1e-4, 0.02)
+    rec = InputRecorder(net)
+    torch.manual_seed(324)
+    out = quiet(sampling, net, tuple(x0.shape), dh, label=label, verbose=False, condition=cond,
+                use_a_precomputed_XT=True, step=4, XT=x0)
+    rec.close()
+    assert len(rec.xs) == 4
+    save("dense_ddpm.npz", eps_first_t50=first, eps_cached_t49=c49, eps_cached_t200=c200, out=out,
+         xs=torch.stack(rec.xs))
+
+
 def fastdpm_ddpm():
     """configs[4], first stage, at FULL size: the reference's `fast_sampling_function_v2` (util_fastdpmv2.py:455-476 ->
     VAR_sampling :307-381) with S = 50, 'var' / 'quadratic' / kappa = 0.5 on the shipped DDPM architecture, B = 1,
@@ -329,8 +360,8 @@ def state_dict_keys():
           (len(net.state_dict()), sum(p.numel() for p in net.parameters())))
 
 
-ALL = (layers, network, network_ddpm, sampling_ddpm, sampling_ddpm_b6, fastdpm_ddpm, refine_ddpm, schedules, metrics,
-       mirror, dataset, state_dict_keys)
+ALL = (layers, network, network_ddpm, sampling_ddpm, sampling_ddpm_b6, dense_ddpm, fastdpm_ddpm, refine_ddpm, schedules,
+       metrics, mirror, dataset, state_dict_keys)
 
 if __name__ == "__main__":
     wanted = sys.argv[1:]                      # no arguments: regenerate everything

@@ -79,3 +79,49 @@ def test_dedup_entry_points_validate_their_arguments_without_a_gpu():
     ga = (p, 64, 100, p, None, 64, p, None, None, None, None, None, 2, 256, 32, 64, None, 64, p, 0, 0, -1)
     assert lib.pdr_gather_add_tiles(*ga, None, 4, None) == EINVAL                       # no tile flags
     assert lib.pdr_gather_add_tiles(*ga, p, 1, None) == EINVAL                          # partial_tpb < tiles per cloud
+
+
+def test_round5_entry_points_validate_their_arguments_without_a_gpu():
+    """pdr_dedup_prepare / pdr_dedup_probe / pdr_gather_add_tiles_twin / pdr_embed_select / pdr_gn_fold's subset arguments
+    / pdr_reverse_step's probe pair: argument errors are decided on the host; and a tile list without its
+    length, a list for a tile height other than 128 and a partial stride smaller than the tiles of a batch element are
+    rejected by every layer entry point, pdr_fused_layer_f16x3 included."""
+    import ctypes as C
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+    p, EINVAL, EUNSUP, OK = 0x1000, _lib.PDR_EINVAL, _lib.PDR_EUNSUPPORTED, _lib.PDR_OK
+    prep = lambda B, m, K, idx=p: lib.pdr_dedup_prepare(idx, p, p, B, m, K, p, p, p, p, p, p, p, p, p, p, p, p, None, None)
+    assert prep(2, 64, 12) == EINVAL and prep(2, 3, 32) == EINVAL and prep(2, 64, 32, None) == EINVAL
+    assert prep(2, 64, 32, 0x1004) == EINVAL                      # index rows move as 16-byte pieces
+    assert prep(2000, 64, 32) == EUNSUP and prep(0, 64, 32) == OK
+    assert lib.pdr_dedup_probe(p, 2, 64, 12, p, None) == EINVAL and lib.pdr_dedup_probe(p, 2, 64, 32, None, None) == EINVAL
+    assert lib.pdr_dedup_probe(p, 0, 64, 32, p, None) == OK
+    tw = lambda **k: lib.pdr_gather_add_tiles_twin(
+        p, 64, 100, p, None, 64, p, None, 2, 256, 32, 64, None, 64, k.get("partial", p), 0, 0, -1, k.get("tv", p),
+        k.get("ptpb", 3), k.get("idx0", p), k.get("Yd", p), k.get("ldyd", 64), k.get("wrow0", p), 32.0, None)
+    assert tw(tv=None) == EINVAL and tw(idx0=None) == EINVAL and tw(Yd=None) == EINVAL and tw(wrow0=None) == EINVAL
+    assert tw(ptpb=2) == EINVAL and tw(ldyd=62) == EINVAL and tw(partial=None) == EINVAL
+    assert lib.pdr_embed_select(p, 64, 10, p, 4, 64, p, 32, None) == EINVAL        # ldo < W
+    assert lib.pdr_embed_select(p, 64, 10, p, 4, 62, p, 64, None) == EUNSUP        # W not a multiple of 4
+    assert lib.pdr_embed_select(p, 64, 10, p, 0, 64, p, 64, None) == OK
+    fold = lambda nv0, tm0, nv1=None, tm1=0, part1=None: lib.pdr_gn_fold(
+        p, 64, 10, 64, 1.0, part1, 64 if part1 else 0, 10 if part1 else 0, 64 if part1 else 0, 1.0, 2, 64 + (64 if part1 else 0),
+        32, 100.0, 1e-5, p, p, p, p, nv0, tm0, nv1, tm1, None)
+    assert fold(p, 0) == EINVAL and fold(p, 11) == EINVAL and fold(None, 0, p, 4) == EINVAL   # second source absent
+    assert fold(p, 8, p, 11, p) == EINVAL
+    assert lib.pdr_reverse_step(p, p, 3, None, p, p, p, p, None, None, None, p, 10, 0, p, None, None) == EINVAL
+    assert lib.pdr_reverse_step(p, p, 3, None, p, p, p, p, None, None, None, p, 0, 0, p, p, None) == OK
+    # layer entry points: tile subsets
+    li = _lib.LayerIn()
+    li.n_seg = 1
+    li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = 0x1000, 64, 64, 1
+    li.rows_per_batch = 1024
+    args = (C.byref(li), 2048, 64, 0x2000, 4, None, 128, 0x3000, 128, None, 128, None)
+    li.tile_list, li.n_tiles = 0x4000, None
+    assert lib.pdr_fused_layer_f16x3(*args) == EUNSUP                          # a list without its length
+    li.rows_per_batch, li.n_tiles = 64, 0x5000
+    assert lib.pdr_fused_layer_f16x3(*args) == EUNSUP                          # 64-row tiles: not a list of 128-row tiles
+    li.rows_per_batch, li.tile_list, li.n_tiles, li.partial_tpb = 1024, None, None, 7
+    assert lib.pdr_fused_layer_f16x3(*args) == EINVAL                          # 8 tiles per batch element, stride 7
+    plain = (C.byref(li), 2048, 64, 0x2000, 128, None, 128, 0x3000, 128, None, 128, None)
+    assert lib.pdr_fused_layer(*plain) == EINVAL

@@ -34,3 +34,17 @@ def test_single_rank_dry_and_world_size_mismatch_message():
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
     bad = _run(["--gpus", "4", "--dry"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert bad.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in (bad.stderr + bad.stdout)
+
+
+def test_eight_rank_dry_run_gathers_in_rank_order():
+    """The 8-GPU job of BASELINE configs[3] / configs[4] without hardware: bench.py starts eight
+    gloo ranks itself, every rank contributes its shard -- the last one short --, and the gathered records arrive
+    concatenated in rank order (generate_samples_distributed.py:84-95), counted by the collective itself."""
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry", "--batch", "6"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["world_size_after_gather"] == 8
+    assert out["records_per_rank"] == [6] * 7 + [3] and out["records_gathered"] == 45
+    assert out["rank_column_sorted"] and out["record_rank_runs"] == [[float(i), 6 if i < 7 else 3] for i in range(8)]

@@ -100,3 +100,25 @@ def test_emd_full_size_is_a_transport_plan(cuda):
     # permuting the points of either cloud does not change the cost beyond the summation-order noise
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(9)).to(cuda)
     assert torch.allclose(emd.earth_mover_distance(a[:, perm].contiguous(), b), fused, rtol=5e-3)
+
+
+@pytest.mark.timeout(900)
+def test_emd_ten_thousand_pair_batch_against_the_oracle(cuda):
+    """Config 3 at its real batch shape: ONE call over 10,000 (2048, 3) pairs -- the kernels stride
+    pairs over the grid (emd_kernel.cu:41,174-196: `for i = blockIdx.x; i < b; i += gridDim.x`), so pairs far into the
+    batch take a code path a 16-pair batch never reaches --, 32 pairs spread over the batch (first / middle / last)
+    against the C oracle at north_star's 1e-4; the same pairs in a batch of their own give the same costs."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pdr_oracle as O
+    P, n = 10000, 2048
+    a = _clouds(P, n, 21, cuda, -0.5, 0.5)
+    b = _clouds(P, n, 22, cuda, -0.5, 0.5)
+    cost = emd.earth_mover_distance(a, b)
+    assert cost.shape == (P,) and bool(torch.isfinite(cost).all())
+    pick = sorted(set(list(range(0, 11)) + list(range(4995, 5005)) + list(range(P - 11, P))))[:32]
+    an, bn = a[pick].cpu().numpy(), b[pick].cpu().numpy()
+    with ThreadPoolExecutor(16) as ex:
+        want = np.array(list(ex.map(lambda i: float(O.emd(an[i:i + 1], bn[i:i + 1])[0]), range(len(pick)))))
+    np.testing.assert_allclose(cost[pick].cpu().numpy(), want, rtol=1e-4)
+    small = emd.earth_mover_distance(a[pick].contiguous(), b[pick].contiguous())
+    assert torch.allclose(small, cost[pick], rtol=1e-6)

@@ -312,7 +312,10 @@ _VARIANTS = [
     ("layerwise_condition_branch", {"PDR_FUSED_OPTS": "FUSE_CONDITION_BRANCH=0"}, False),
     ("torch_global_pointnet", {"PDR_FUSED_OPTS": "FUSE_GLOBAL_PNET=0"}, False),
     ("whole_neighbourhoods", {"PDR_FUSED_OPTS": "DEDUP=0"}, False),
-    ("unsorted_queries", {"PDR_FUSED_OPTS": "DEDUP_SORT=0"}, False),
+    # the round-4 forms of the launches round 5 fused (cross-checks of the default)
+    ("plan_in_six_launches", {"PDR_FUSED_OPTS": "FUSED_PLAN=0"}, True),
+    ("weighted_moments_launches", {"PDR_FUSED_OPTS": "TWIN_STATS=0"}, False),
+    ("patch_rows_launch", {"PDR_FUSED_OPTS": "FUSED_PATCH=0"}, True),
     ("dedup_from_256_queries", {"PDR_FUSED_OPTS": "DEDUP_MIN_QUERIES=256"}, False),
     ("decoder_maps_in_place", {"PDR_FUSED_OPTS": "AHEAD_DECODER_MAPS=0"}, False),
 ]
@@ -347,7 +350,7 @@ def test_ddpm_forward_with_every_non_default_variant(cuda, tmp_path):
     base = results["default"]
     assert all(bool(torch.isfinite(v).all()) for v in base.values())
     for name, _, identical in _VARIANTS:
-        for call in ("first", "cached"):
+        for call in ("first", "cached", "mixed"):
             got, want = results[name][call], base[call]
             if identical:
                 assert torch.equal(got, want), (name, call, float((got - want).abs().max()))
@@ -1198,20 +1201,25 @@ def test_layer_tile_subset_matches_the_whole_layer_on_its_tiles(cuda, shape):
     assert bool((Y2 == -5.0).all())
 
 
-@pytest.mark.parametrize("cloud", ["noise", "surface"])
+@pytest.mark.parametrize("cloud", ["noise", "mixed", "surface"])
 def test_one_point_neighbourhoods_evaluated_once_match_the_whole_evaluation(cuda, cloud, monkeypatch):
     """DEDUP on vs off on the DDPM configuration: eps of a cached step agrees to fp32 summation order on a noise-like
-    x_t (most tiles skipped) and on a surface-like one (few skipped), and both agree with the layer-by-layer network."""
+    x_t (most tiles skipped), on x_t = q_sample(torus, t = 75) -- a MIXED plan: 30-90 % of the tiles walked, every block
+    with walked and skipped tiles side by side -- and on the finished surface (t = 0: nearly every tile walked, the
+    per-query chain idle); all three agree with the layer-by-layer network."""
     from tests import parity
+    from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG, q_sample, synthetic_surface_batch
     torch.manual_seed(0)
     net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
     fused = FN.FusedCloudConditionNet(net)
     x, cond, label = synthetic_batch(2, seed=5, device=cuda)
-    if cloud == "surface":
-        x = 0.5 * x / x.norm(dim=2, keepdim=True)            # points on a sphere: full balls at the coarse levels
-        cond = torch.cat([x[:, :1536] * 1.0, x[:, :1536] * torch.tensor([1.0, 1.0, -1.0], device=cuda)], 1)
-        cond = torch.cat([cond, torch.ones(2, 3072, 1, device=cuda)], 2).contiguous()
     ts = torch.tensor([300.0, 40.0], device=cuda)
+    if cloud != "noise":
+        t = 75 if cloud == "mixed" else 0
+        x0, cond, label = synthetic_surface_batch(2, seed=5, device=cuda)
+        # (_cached_eps evaluates the step on 0.9 x)
+        x = q_sample(x0, t, util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG), seed=5) / 0.9
+        ts = torch.full((2,), float(t + 1), device=cuda)
     plans = []
     init = FN.Dedup.__init__
 
@@ -1225,7 +1233,340 @@ def test_one_point_neighbourhoods_evaluated_once_match_the_whole_evaluation(cuda
         outs[on], ref = _cached_eps(net, fused, x, cond, ts, label)
     torch.cuda.synchronize()
     walked = sum(int(p.n_tiles) for p in plans) / float(sum(p.B * p.tpb for p in plans))
-    assert plans and (walked < 0.6 if cloud == "noise" else walked > 0.5), walked
+    assert plans and {"noise": walked < 0.3, "mixed": 0.3 < walked < 0.9, "surface": walked > 0.9}[cloud], walked
     parity.check("dedup:%s:on_vs_off" % cloud, "hip", outs[True], outs[False], 2e-5)
     err = ((outs[True] - ref).abs() / (ref.abs() + 1.0))
     assert err.max() < 1e-2 and (err < 1e-3).float().mean() > 0.99, (err.max(), (err < 1e-3).float().mean())
+
+
+def _surface_sampler_inputs(cuda, B):
+    from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG, synthetic_surface_batch
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
+    fused = FN.FusedCloudConditionNet(net)
+    x0, cond, label = synthetic_surface_batch(B, seed=3, device=cuda)
+    return net, fused, util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG), x0, cond, label
+
+
+def test_adaptive_sampler_picks_the_form_of_each_step_from_the_probe(cuda):
+    """GraphedReverseSampler(neighbourhoods='adaptive') on the DDPM configuration: restarted on a finished surface
+    (use_a_precomputed_XT, step = 6: full balls) it replays the step with every neighbourhood evaluated, from noise the
+    deduplicated one; the published walked share matches the plans'; and whichever form a step takes, the samples equal
+    those of the two fixed forms to fp32 summation order (same CPU noise stream)."""
+    net, fused, dh, x0, cond, label = _surface_sampler_inputs(cuda, 2)
+    outs, counts = {}, {}
+    for mode in ("adaptive", "once", "whole"):
+        s = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True, neighbourhoods=mode)
+        torch.manual_seed(7)
+        outs[mode] = s.sample((2, 2048, 3), cond, label, use_a_precomputed_XT=True, step=6, XT=x0)
+        counts[mode] = dict(s.mode_counts)
+        if mode == "adaptive":
+            assert s.walked_share is not None and s.walked_share > 0.8, s.walked_share
+    assert counts["adaptive"]["whole"] >= 4 and counts["once"]["whole"] == 0 and counts["whole"]["once"] == 0, counts
+    for mode in ("once", "whole"):
+        assert _rel(outs["adaptive"], outs[mode]) < 2e-4, mode
+    # from noise: the deduplicated form, chosen from the first step's probe
+    s = GraphedReverseSampler(fused, util.calc_diffusion_hyperparams(5, 1e-4, 0.02), noise='cpu', use_graph=True)
+    torch.manual_seed(7)
+    out = s.sample((2, 2048, 3), cond, label)
+    assert s.mode_counts["whole"] == 0 and s.mode_counts["once"] == 4 and s.walked_share < 0.3, (s.mode_counts, s.walked_share)
+    assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.timeout(600)
+def test_captured_steps_replayed_on_changing_inputs_match_eager_whole_evaluations(cuda):
+    """Soak: ONE sampler, its two captured steps, 200 replays; before every replay x_t is overwritten
+    with the next point of a trajectory's marginal (q_sample of a torus at t = 199 ... 0: noise -> mixed -> surface, so
+    the tile lists, the per-query chains and the adaptive switch all change under the same graphs) and the step counter
+    set to t; after every 20th replay eps-equivalent state -- the updated x -- is compared with an EAGER step of a
+    sampler that evaluates every neighbourhood (no graph, no tile subset), from the same x_t, same noise."""
+    from point_diffusion_refinement_amd.pointnet2.configs import q_sample
+    net, fused, dh, x0, cond, label = _surface_sampler_inputs(cuda, 2)
+    s = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True)
+    import copy
+    # (its own copy of the module: a network's retained condition features belong to one sampler at a time)
+    ref = GraphedReverseSampler(FN.FusedCloudConditionNet(copy.deepcopy(net)), dh, noise='cpu', use_graph=False,
+                                neighbourhoods='whole')
+    torch.manual_seed(1)
+    s.begin((2, 2048, 3), cond, label, x_T=q_sample(x0, 200, dh, seed=3), start_step=200)
+    ref.begin((2, 2048, 3), cond, label, x_T=q_sample(x0, 200, dh, seed=3), start_step=200)
+    worst, modes = 0.0, []
+    for t in range(199, -1, -1):
+        xt = q_sample(x0, t, dh, seed=3)
+        for smp in (s,) + ((ref,) if t % 20 == 0 else ()):
+            smp._x.copy_(xt)
+            smp._t.fill_(t)
+            smp._ts.fill_(float(t))
+            smp.remaining = t + 1
+        torch.manual_seed(1000 + t)
+        s.advance(1)
+        modes.append(s._mode)
+        if t % 20 == 0:
+            torch.manual_seed(1000 + t)
+            ref.advance(1)
+            torch.cuda.synchronize()
+            worst = max(worst, _rel(s._x, ref._x))
+            assert _rel(s._x, ref._x) < 5e-5, (t, modes[-1], _rel(s._x, ref._x))
+    assert "once" in modes and "whole" in modes and modes[0] == "once" and modes[-1] == "whole", (modes[0], modes[-1])
+    assert set(s._graphs) == {"once", "whole"}
+
+
+# ---- round 5: the launches of the deduplicated step, fused ------------------------------------------------------------
+@pytest.mark.parametrize("B,m,K", [(3, 1024, 32), (5, 256, 8), (2, 2048, 16), (33, 64, 32), (2, 16, 32)])
+def test_dedup_prepare_equals_sort_gathers_and_plan(cuda, B, m, K):
+    """pdr_dedup_prepare = pdr_dedup_sort + the row gathers of idx / counts / xyz + pdr_dedup_plan on the sorted arrays,
+    bit for bit, in one launch; nvalid = [valid tiles | first weighted query] per cloud; the probe counters accumulate
+    (pdr_dedup_probe adds the same two numbers without a plan)."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    n_src = 500
+    idx, counts = _ball_like_neighbourhoods(B, m, K, n_src, dev, 3 * m + K, 0.2, 3)
+    if B > 2:
+        counts[1].clamp_(max=1)                      # a cloud without any real neighbourhood ...
+        counts[2].fill_(5)                           # ... and one with nothing else
+    xyz = torch.randn(B, m, 3, device=dev)
+    qpt, tpb = 128 // K, m * K // 128
+    i32 = dict(dtype=torch.int32, device=dev)
+    # round-4 pipeline
+    perm, inv, rows = (torch.empty(B, m, **i32) for _ in range(3))
+    _lib.check(lib.pdr_dedup_sort(counts.data_ptr(), B, m, perm.data_ptr(), inv.data_ptr(), rows.data_ptr(), st), "sort")
+    pl = perm.long()
+    idx_s = torch.gather(idx, 1, pl[:, :, None].expand(-1, -1, K)).contiguous()
+    cnt_s = torch.gather(counts, 1, pl).contiguous()
+    xyz_s = torch.gather(xyz, 1, pl[:, :, None].expand(-1, -1, 3)).contiguous()
+    idx0, row_w = torch.empty(B, m, **i32), torch.empty(B * m, device=dev)
+    tv, tl, nt = torch.empty(B * tpb, dtype=torch.uint8, device=dev), torch.full((B * tpb,), -1, **i32), torch.empty(1, **i32)
+    _lib.check(lib.pdr_dedup_plan(idx_s.data_ptr(), cnt_s.data_ptr(), B, m, K, idx0.data_ptr(), row_w.data_ptr(),
+                                  tv.data_ptr(), tl.data_ptr(), nt.data_ptr(), st), "plan")
+    # one launch
+    perm2, inv2, rows2, idx02 = (torch.full((B, m), -7, **i32) for _ in range(4))
+    idx_s2, cnt_s2, xyz_s2 = torch.full_like(idx, -7), torch.full_like(counts, -7), torch.full_like(xyz, -7.0)
+    row_w2 = torch.full((B * m,), -7.0, device=dev)
+    tv2, tl2, nt2 = torch.full((B * tpb,), 9, dtype=torch.uint8, device=dev), torch.full((B * tpb,), -1, **i32), torch.zeros(1, **i32)
+    nvalid = torch.full((2, B), -7, **i32)
+    acc = torch.tensor([5, 11], **i32)
+    _lib.check(lib.pdr_dedup_prepare(idx.data_ptr(), counts.data_ptr(), xyz.data_ptr(), B, m, K, perm2.data_ptr(),
+                                     inv2.data_ptr(), rows2.data_ptr(), idx_s2.data_ptr(), cnt_s2.data_ptr(),
+                                     xyz_s2.data_ptr(), idx02.data_ptr(), row_w2.data_ptr(), tv2.data_ptr(),
+                                     tl2.data_ptr(), nt2.data_ptr(), nvalid.data_ptr(), acc.data_ptr(), st), "prepare")
+    torch.cuda.synchronize()
+    n = int(nt)
+    for name, a, b in (("perm", perm, perm2), ("inv", inv, inv2), ("rows", rows, rows2), ("idx", idx_s, idx_s2),
+                       ("counts", cnt_s, cnt_s2), ("xyz", xyz_s, xyz_s2), ("idx0", idx0, idx02), ("row_w", row_w, row_w2),
+                       ("tile_valid", tv, tv2), ("n_tiles", nt, nt2), ("tile_list", tl[:n], tl2[:n])):
+        assert torch.equal(a, b), name
+    assert bool((tl2[n:] == -1).all())
+    nv = tv.view(B, tpb).sum(1).int()
+    assert torch.equal(nvalid[0], nv) and torch.equal(nvalid[1], nv * qpt)
+    # sorted queries: a cloud's valid tiles are its first ones
+    assert torch.equal(tv.view(B, tpb).bool(), torch.arange(tpb, device=dev)[None, :] < nv[:, None])
+    assert acc.tolist() == [5 + n, 11 + B * tpb]
+    _lib.check(lib.pdr_dedup_probe(counts.data_ptr(), B, m, K, acc.data_ptr(), st), "probe")
+    assert acc.tolist() == [5 + 2 * n, 11 + 2 * B * tpb]
+
+
+def test_gather_add_tiles_twin_equals_the_three_launches(cuda):
+    """pdr_gather_add_tiles_twin: the main tiles as pdr_gather_add_tiles (same bits), the per-query rows as the K = 1
+    pdr_gather_add on the first neighbours (same bits), their weighted moments as pdr_weighted_moments (fp32 summation
+    order), in one launch -- on sorted queries, with and without empty balls and a written column window."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    B, m, K, Cout, n_src, relu_col0 = 3, 1024, 32, 96, 700, 64
+    ld = Cout
+    g = torch.Generator(device=dev).manual_seed(3)
+    U = torch.randn(B * n_src + 1, ld, device=dev, generator=g)
+    V2 = torch.randn(B * m, 2 * ld, device=dev, generator=g)
+    idx_u, counts_u = _ball_like_neighbourhoods(B, m, K, n_src, dev, 77, 0.15, 3)
+    fm = FN.SortedQueries(idx_u, counts_u, torch.randn(B, m, 3, device=dev))
+    dd, idx, counts = fm.plan, fm.idx, fm.counts
+    assert dd is not None and 0 < int(dd.n_tiles) < B * dd.tpb
+    tpb, ptpb = dd.tpb, dd.ptpb
+    for has_counts, (ycol0, ycols) in ((True, (0, -1)), (False, (32, 32))):
+        cptr = counts.data_ptr() if has_counts else None
+        tabs = (U.data_ptr(), ld, n_src, V2.data_ptr(), V2.data_ptr() + 4 * ld if has_counts else None, 2 * ld)
+        ncol = Cout if ycols < 0 else ycols
+        Ya, Yb = (torch.full((B * m * K, ncol), -3.0, device=dev) for _ in range(2))
+        pa, pb = (torch.full((B * ptpb, Cout, 2), float("nan"), device=dev) for _ in range(2))
+        _lib.check(lib.pdr_gather_add_tiles(*tabs, idx.data_ptr(), cptr, None, None, None, None, B, m * K, K, Cout,
+                                            Ya.data_ptr(), ncol, pa.data_ptr(), relu_col0, ycol0, ycols,
+                                            dd.tile_valid.data_ptr(), ptpb, st), "tiles")
+        Yda = torch.empty(B * m, ld, device=dev)
+        _lib.check(lib.pdr_gather_add(*tabs, dd.idx0.data_ptr(), cptr, None, None, None, None, B, m, 1, Cout,
+                                      Yda.data_ptr(), ld, None, relu_col0, 0, -1, st), "gather_add")
+        _lib.check(lib.pdr_weighted_moments(Yda.data_ptr(), ld, B, m, Cout, relu_col0, dd.row_w.data_ptr(), pa.data_ptr(),
+                                            ptpb, tpb, dd.tile_valid.data_ptr(), st), "weighted_moments")
+        Ydb = torch.full((B * m, ld), -3.0, device=dev)
+        _lib.check(lib.pdr_gather_add_tiles_twin(*tabs, idx.data_ptr(), cptr, B, m * K, K, Cout, Yb.data_ptr(), ncol,
+                                                 pb.data_ptr(), relu_col0, ycol0, ycols, dd.tile_valid.data_ptr(), ptpb,
+                                                 dd.idx0.data_ptr(), Ydb.data_ptr(), ld, dd.wrow0.data_ptr(), float(K), st),
+                   "twin")
+        torch.cuda.synchronize()
+        assert torch.equal(Ya, Yb) and torch.equal(Yda, Ydb)
+        va, vb = pa.view(B, ptpb, Cout, 2), pb.view(B, ptpb, Cout, 2)
+        valid = dd.tile_valid.view(B, tpb).bool()
+        assert torch.equal(va[:, :tpb][valid], vb[:, :tpb][valid])
+        assert bool(torch.isnan(vb[:, :tpb][~valid]).all())             # skipped tiles: not written (nobody zeroes them)
+        ta, tb = va[:, tpb:].double(), vb[:, tpb:].double()
+        assert not bool(torch.isnan(tb).any())
+        assert float(((ta - tb).abs() / (ta.abs() + 1.0)).max()) < 2e-5
+
+
+@pytest.mark.parametrize("rpb,Cin,Cout", [(2048, 32, 32), (1024, 64, 128), (256, 128, 128), (64, 256, 128), (16, 512, 512),
+                                          (1024, 41, 64)])
+def test_layer_weighted_statistics(cuda, rpb, Cin, Cout):
+    """pdr_layer_in_t.wrow0 / wmul: Y as without them (same bits); partial rows = wmul x the moments of the rows
+    r >= wrow0[b] -- wave-specialised tiles (128 / 64 rows) and the uniform kernel (32-row tiles), thresholds at 0, inside a
+    tile, on a tile boundary and past the end."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    B = 4
+    g = torch.Generator(device=dev).manual_seed(rpb + Cout)
+    P, ldx, ldw = B * rpb, (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    X = torch.randn(P, ldx, device=dev, generator=g)
+    Wt = torch.randn(Cin, ldw, device=dev, generator=g) * 0.1
+    bias = torch.randn(Cout, device=dev, generator=g)
+    scale, shift = torch.rand(B, Cin, device=dev, generator=g) + 0.5, torch.randn(B, Cin, device=dev, generator=g)
+    li = _lib.LayerIn()
+    li.n_seg = 1
+    li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, ldx, 1
+    li.scale, li.shift, li.pre_relu, li.post_relu, li.rows_per_batch = scale.data_ptr(), shift.data_ptr(), 0, 1, rpb
+    tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+    tpb = (rpb + tm - 1) // tm
+    relu_col0 = Cout // 2
+    Y0 = torch.empty(P, ldw, device=dev)
+    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout, Y0.data_ptr(),
+                                   ldw, None, relu_col0, st), "plain")
+    thr = torch.tensor([0, min(rpb, 5), min(rpb, tm) if tpb > 1 else rpb // 2, rpb + 3], dtype=torch.int32, device=dev)
+    ptpb, off = tpb + 7, 5                                   # rows of another launch in front, as in a deduplicated layer
+    part = torch.full((B * ptpb, Cout, 2), float("nan"), device=dev)
+    li.wrow0, li.wmul, li.partial_tpb = thr.data_ptr(), 32.0, ptpb
+    Y1 = torch.empty(P, ldw, device=dev)
+    _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout, Y1.data_ptr(),
+                                   ldw, part.data_ptr() + 4 * off * Cout * 2, relu_col0, st), "weighted")
+    torch.cuda.synchronize()
+    assert torch.equal(Y0[:, :Cout], Y1[:, :Cout])
+    f = Y0[:, :Cout].double().view(B, rpb, Cout).clone()
+    f[:, :, relu_col0:].clamp_(min=0)
+    w = (torch.arange(rpb, device=dev)[None, :] >= thr[:, None].long()).double()[:, :, None] * 32.0
+    pv = part.view(B, ptpb, Cout, 2)
+    assert bool(torch.isnan(pv[:, :off]).all()) and bool(torch.isnan(pv[:, off + tpb:]).all())
+    for t in range(tpb):
+        rows = slice(t * tm, min((t + 1) * tm, rpb))
+        want = torch.stack([(w[:, rows] * f[:, rows]).sum(1), (w[:, rows] * f[:, rows] ** 2).sum(1)], -1)
+        got = pv[:, off + t].double()
+        assert float(((got - want).abs() / (want.abs() + 1.0)).max()) < 2e-5, t
+
+
+def test_gn_fold_skips_the_invalid_tile_range(cuda):
+    """pdr_gn_fold(nvalid, tpb_main): rows [nvalid[b], tpb_main) of batch element b are not read -- NaN there, same
+    scale / shift (bits) as the fold over the same rows with zeros in their place; both partial sources, both the
+    small and the 16-row form."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(9)
+    for B, tpb_main, extra, C0, C1, G in ((3, 40, 3, 64, 0, 32), (2, 512, 16, 32, 0, 32), (3, 24, 2, 32, 96, 32)):
+        tpb = tpb_main + extra
+        C = C0 + C1
+        nv = torch.randint(0, tpb_main + 1, (B,), generator=g, device=dev).int()
+        nv[0] = 0
+        nv[-1] = tpb_main
+        skip = (torch.arange(tpb, device=dev)[None, :] >= nv[:, None]) & (torch.arange(tpb, device=dev)[None, :] < tpb_main)
+        parts = []
+        for Cp in (C0, C1):
+            if Cp:
+                p = torch.rand(B, tpb, Cp, 2, device=dev, generator=g) + 0.5
+                parts.append(p)
+        gamma, beta = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)
+        outs = []
+        for fill, use_nv in ((0.0, False), (float("nan"), True)):
+            ps = []
+            for p in parts:
+                q = p.clone()
+                q[skip] = fill
+                ps.append(q.view(B * tpb, -1, 2).contiguous())
+            scale, shift = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+            second = (ps[1].data_ptr(), C1, tpb, C1, 4.0) if C1 else (None, 0, 0, 0, 1.0)
+            nva = (nv.data_ptr(), tpb_main) if use_nv else (None, 0)
+            _lib.check(lib.pdr_gn_fold(ps[0].data_ptr(), C0, tpb, C0, 1.0, *second, B, C, G, 1000.0, 1e-5,
+                                       gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), *nva,
+                                       *(nva if C1 else (None, 0)), st), "gn_fold")
+            outs.append((scale, shift))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert bool(torch.isfinite(outs[1][0]).all())
+
+
+@pytest.mark.parametrize("D,K", [(32, 32), (64, 32), (128, 8)])
+def test_pooled_launch_patches_the_skipped_queries(cuda, D, K):
+    """pdr_layer_in_t.patch_values / patch_w on a pooled launch over a tile subset with a row map = the same launch
+    without them followed by pdr_patch_rows: identical output rows."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    B, m, Cin = 3, 512, 64
+    rpb = m * K
+    P = B * rpb
+    g = torch.Generator(device=dev).manual_seed(D + K)
+    idx_u, counts_u = _ball_like_neighbourhoods(B, m, K, 300, dev, D, 0.2, 3)
+    fm = FN.SortedQueries(idx_u, counts_u, torch.randn(B, m, 3, device=dev))
+    dd, counts = fm.plan, fm.counts
+    X = torch.randn(P, Cin, device=dev, generator=g)
+    Wt = torch.randn(Cin, D, device=dev, generator=g) * 0.2
+    bias = torch.randn(D, device=dev, generator=g)
+    V = torch.randn(P, D, device=dev, generator=g)
+    Vd = torch.randn(B * m, D, device=dev, generator=g)
+    vs, vt = torch.rand(B, D, device=dev, generator=g) + 0.5, torch.randn(B, D, device=dev, generator=g)
+    li = _lib.LayerIn()
+    li.n_seg = 1
+    li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, Cin, 1
+    li.rows_per_batch = rpb
+    li.tile_list, li.n_tiles, li.out_rows = dd.tile_list.data_ptr(), dd.n_tiles.data_ptr(), fm.perm_rows.data_ptr()
+
+    def pool(out):
+        _lib.check(lib.pdr_fused_layer_pool(ctypes.byref(li), P, Cin, Wt.data_ptr(), D, bias.data_ptr(), D, V.data_ptr(),
+                                            D, vs.data_ptr(), vt.data_ptr(), 1, counts.data_ptr(), K, out.data_ptr(), D,
+                                            st), "pool")
+    a = torch.full((B * m, D), -9.0, device=dev)
+    pool(a)
+    _lib.check(lib.pdr_patch_rows(Vd.data_ptr(), D, vs.data_ptr(), vt.data_ptr(), 1, dd.row_w.data_ptr(), B, m, D,
+                                  a.data_ptr(), D, fm.perm_rows.data_ptr(), st), "patch_rows")
+    b = torch.full((B * m, D), -9.0, device=dev)
+    li.patch_values, li.patch_ld, li.patch_w = Vd.data_ptr(), D, dd.row_w.data_ptr()
+    pool(b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not bool((b == -9.0).any())
+
+
+def test_embed_select_and_step_table(cuda):
+    """The step-embedding table of a schedule holds, row by row, the bits the three-launch chain produces for that step;
+    pdr_embed_select broadcasts the row of the device step counter (clamped) to the batch; a forward with the table
+    equals a forward with the chain bit for bit."""
+    net, fused = _pair(small_fused_config(), 31, cuda)
+    T, B = 37, 3
+    ts_all = torch.arange(T, dtype=torch.float32, device=cuda) * 1.5
+    table = fused.build_step_table(ts_all)
+    assert table is not None and table.shape[0] == T
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    t_dev = torch.zeros(1, dtype=torch.int64, device=cuda)
+    for t in (0, 5, 36, 50, -2):
+        t_dev.fill_(t)
+        tc = min(max(t, 0), T - 1)
+        assert fused._embed_linear_chain(ts_all[tc:tc + 1].expand(B))
+        want = fused.bank.out["t"].clone()
+        out = torch.full((B, table.shape[1]), -1.0, device=cuda)
+        _lib.check(lib.pdr_embed_select(table.data_ptr(), table.shape[1], T, t_dev.data_ptr(), B, table.shape[1],
+                                        out.data_ptr(), out.shape[1], st), "embed_select")
+        assert torch.equal(out, want), t
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 3, generator=g).to(cuda)
+    cond = torch.cat([torch.rand(2, 384, 3, generator=g) * 2 - 1, torch.ones(2, 384, 1)], 2).to(cuda)
+    label = torch.tensor([1, 7], device=cuda)
+    t_dev.fill_(9)
+    ts = ts_all[9:10].expand(2)
+    with torch.no_grad():
+        a = fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        a = fused(x * 0.9, cond, ts=ts, label=label, use_retained_condition_feature=True).clone()
+        fused.step_table = (table, t_dev)
+        b = fused(x * 0.9, cond, ts=ts, label=label, use_retained_condition_feature=True).clone()
+        fused.step_table = None
+    assert torch.equal(a, b)

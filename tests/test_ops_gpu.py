@@ -414,17 +414,24 @@ def test_reverse_step_update_bookkeeping_and_noise(cuda, mode):
     tau = (torch.arange(T, dtype=torch.float32) * 1.75 + 0.125).to(cuda)
     st = torch.cuda.current_stream().cuda_stream
     ticket = torch.zeros(1, dtype=torch.int32, device=cuda)
+    acc = torch.zeros(2, dtype=torch.int32, device=cuda)
+    published = torch.zeros(2, dtype=torch.int32).pin_memory()             # pinned host memory, written by the kernel
     for step, table in ((T - 1, None), (7, tau), (0, None)):
         t = torch.tensor([step], dtype=torch.int64, device=cuda)
         ts = torch.full((1,), -5.0, device=cuda)
         A, Bc, C = a[step], b[step], c[step]
         want = (x - A * eps) / Bc + C * z if mode == 0 else (x * A) + (Bc * eps + C * z)
         got = x.clone()
+        acc.copy_(torch.tensor([17 + step, 40], dtype=torch.int32))
         _lib.check(lib.pdr_reverse_step(got.data_ptr(), eps.data_ptr(), eps.stride(1), z.data_ptr(), a.data_ptr(),
                                         b.data_ptr(), c.data_ptr(), t.data_ptr(), None if table is None else table.data_ptr(),
-                                        ts.data_ptr(), None, ticket.data_ptr(), B * N, mode, st), "reverse_step")
+                                        ts.data_ptr(), None, ticket.data_ptr(), B * N, mode, acc.data_ptr(),
+                                        published.data_ptr(), st), "reverse_step")
         assert torch.equal(got, want), (mode, step, float((got - want).abs().max()))
         assert int(t) == step - 1 and int(ticket) == 0
+        # the neighbourhood probe of the step: published to the (host-visible) slot and reset by the same last workgroup
+        torch.cuda.synchronize()
+        assert published.tolist() == [17 + step, 40] and acc.tolist() == [0, 0]
         expect_ts = -5.0 if step == 0 else (float(tau[step - 1]) if table is not None else float(step - 1))
         assert float(ts) == expect_ts
     # in-kernel noise: isolate z through x = 0, eps = 0, coefficients (a, b, c) = (1, 1, 1)
@@ -438,7 +445,7 @@ def test_reverse_step_update_bookkeeping_and_noise(cuda, mode):
         rng = torch.tensor([key, number], dtype=torch.int64, device=cuda)
         _lib.check(lib.pdr_reverse_step(xs.data_ptr(), zero_eps.data_ptr(), 3, None, one.data_ptr(), one.data_ptr(),
                                         one.data_ptr(), t.data_ptr(), None, None, rng.data_ptr(), ticket.data_ptr(),
-                                        Bn * Nn, mode, st), "reverse_step")
+                                        Bn * Nn, mode, None, None, st), "reverse_step")
         assert rng.tolist() == [key, number + 1] and int(t) == 2
         return xs.flatten().double().cpu()
     z0, z0b, z1, zk = draw(1234567, 0), draw(1234567, 0), draw(1234567, 1), draw(-99, 0)

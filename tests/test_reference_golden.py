@@ -304,6 +304,98 @@ def test_full_ddpm_config_sampling_b6_t3_has_unflipped_clouds(be):
         assert all(n > 0 for n in checked.values()), checked
 
 
+def test_full_ddpm_config_dense_and_mixed_neighbourhoods_match_reference(be):
+    """The DENSE / MIXED-ball regime against the reference (make_golden.py dense_ddpm(): shipped DDPM architecture, B = 2,
+    x_0 = synthetic tori, x_t = q_sample(x_0, t)): forwards at t = 50 (first call), 49 and 200 (cached), and the
+    reference's `sampling` restarted from a precomputed x at step 4 (util.py:217-222) -- four calls that end on the
+    surface.  cpu-oracle: the product network / loop over the oracle ops (forwards bit-identical).  hip: layer-by-layer,
+    fused f32 and split-f16 with the one-point neighbourhoods evaluated once -- on a MIXED plan (30-90 % of the tiles
+    walked at t = 49, asserted) and a sparse one (t = 200) -- at the network-level bars; the restarted loop with the
+    deduplicated step forced ('once': nearly every tile walked, the per-query chains idle beside them), with the sampler's
+    own per-step choice ('adaptive': the whole evaluation here) and eagerly, judged like the other full-size loops."""
+    from point_diffusion_refinement_amd.pointnet2.configs import ddpm_pointnet_config
+    g = gold("dense_ddpm.npz")
+    x0, cond, label = I.dense_inputs(2)
+    xt = {t: I.dense_xt(x0, t) for t in (50, 49, 200)}
+    x0, cond, label = be.to(x0, cond, label)
+    xt = {t: be.to(v) for t, v in xt.items()}
+    one = torch.ones(2, device=be.device)
+    net = fill_deterministic(PointNet2CloudCondition(ddpm_pointnet_config()), 31).eval().to(be.device)
+    calls = (("eps_first_t50", 50), ("eps_cached_t49", 49), ("eps_cached_t200", 200))
+
+    def forwards(model):
+        model.reset_cond_features()
+        with torch.no_grad(), be.ops():
+            return {k: model(xt[t], cond, ts=t * one, label=label, use_retained_condition_feature=True).clone()
+                    for k, t in calls}
+    dh = util.calc_diffusion_hyperparams(1000, 1e-4, 0.02)
+    ref_xs = [torch.from_numpy(a) for a in g["xs"]]
+    out = forwards(net)
+    net.reset_cond_features()
+    rec = parity.InputRecorder(net)
+    with torch.no_grad(), be.ops():
+        torch.manual_seed(324)
+        samp = _quiet(util.sampling, net, tuple(x0.shape), dh, label=label, verbose=False, condition=cond,
+                      use_a_precomputed_XT=True, step=4, XT=x0)
+    rec.close()
+    if be.kind == "cpu-oracle":
+        for k, _ in calls:
+            assert np.array_equal(out[k].numpy(), g[k]), k
+        be.close(samp, g["out"], "ddpm_full:dense_sampling", 50)
+        return
+    for k, t in calls:
+        be.net_close(out[k], g[k], "ddpm_full:dense_%s" % k, xt[t])
+    assert torch.equal(rec.xs[0], ref_xs[0])                               # the same restart point: same CPU noise
+    cfg = ddpm_pointnet_config()
+    _judge_trajectory(be, cfg, cond, "ddpm_full:dense_sampling:layer_by_layer", samp, rec.xs, ref_xs, g["out"])
+    from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
+    from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedReverseSampler
+    plans, init = [], FN.Dedup.__init__
+
+    def recording(self, *a, **k):
+        init(self, *a, **k)
+        plans.append(self)
+    FN.Dedup.__init__ = recording
+    try:
+        for precision in ("f32", "split_f16"):
+            fused = FN.FusedCloudConditionNet(net, precision=precision)
+            got, shares = {}, {}
+            fused.reset_cond_features()
+            with torch.no_grad():
+                for k, t in calls:
+                    del plans[:]
+                    got[k] = fused(xt[t], cond, ts=t * one, label=label, use_retained_condition_feature=True).clone()
+                    torch.cuda.synchronize()
+                    shares[k] = sum(int(p.n_tiles) for p in plans) / max(1.0, float(sum(p.B * p.tpb for p in plans)))
+            tag = "ddpm_full_fused" if precision == "f32" else "ddpm_full_split_f16"
+            for k, t in calls:
+                be.net_close(got[k], g[k], "%s:dense_%s" % (tag, k), xt[t])
+            if not FAKE_HIP:
+                # a MIXED plan is what t = 49 tests: walked and skipped tiles side by side in every block
+                assert 0.3 < shares["eps_cached_t49"] < 0.9 and shares["eps_cached_t200"] < 0.3, shares
+                parity.RECORDS[-1].setdefault("extra", {})
+                parity.RECORDS[-1]["tiles_walked_frac"] = {k: round(v, 4) for k, v in shares.items()}
+    finally:
+        FN.Dedup.__init__ = init
+    sig4 = dh["Sigma"][4].to(be.device)
+    for precision, use_graph, form in (("f32", True, "once"), ("f32", True, "adaptive"), ("f32", False, "once"),
+                                       ("split_f16", True, "once")):
+        fused = FN.FusedCloudConditionNet(net, precision=precision)
+        sampler = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=use_graph, neighbourhoods=form)
+        torch.manual_seed(324)
+        torch.normal(0, 1, size=tuple(x0.shape))                           # util.sampling draws (and discards) x_T first
+        x_start = x0 + sig4 * torch.normal(0, 1, size=tuple(x0.shape)).to(be.device)
+        sampler.begin(tuple(x0.shape), cond, label, x_T=x_start, start_step=3)
+        xs = [ref_xs[0]]
+        while sampler.remaining > 0:
+            xs.append(sampler._x.detach().cpu().clone())
+            sampler.advance(1)
+        name = "%s_%s_%s" % ("fused" if precision == "f32" else "split_f16", "graph" if use_graph else "eager", form)
+        _judge_trajectory(be, cfg, cond, "ddpm_full:dense_sampling:" + name, sampler.finish(), xs, ref_xs, g["out"])
+        if form == "adaptive" and not FAKE_HIP:
+            assert sampler.mode_counts["whole"] == 3 and sampler.mode_counts["once"] == 0, sampler.mode_counts
+
+
 def test_full_ddpm_config_fastdpm_s50_matches_reference(be):
     """configs[4], first stage, at FULL size against the REFERENCE: `fast_sampling_function_v2` S = 50, 'var' /
     'quadratic' / kappa = 0.5 (util_fastdpmv2.py:307-381, 455-476) on the shipped DDPM architecture, B = 1, CPU noise

@@ -166,8 +166,8 @@ def step_kernel_table(sampler, reps=3):
     # every launch over ALL its tiles: the algorithmic flops / bytes of _work() are those of whole launches, and a
     # kernel's roofline is a property of the kernel, not of how many of its tiles an input happens to need (the
     # headline step evaluates one-point neighbourhoods once: fused_network.DEDUP, a device-side tile subset)
-    from point_diffusion_refinement_amd.pointnet2 import fused_network as _FN
-    saved_dedup, _FN.DEDUP = _FN.DEDUP, False
+    saved_mode, sampler._mode = sampler._mode, 'whole'
+    saved_nb, sampler.neighbourhoods = sampler.neighbourhoods, 'whole'     # (no probe launches in the timed steps)
     records = []
     installed = []
     for name in _TIMED:
@@ -193,7 +193,7 @@ def step_kernel_table(sampler, reps=3):
                 sampler._step()           # eager: the graph is not involved
         torch.cuda.synchronize()
     finally:
-        _FN.DEDUP = saved_dedup
+        sampler._mode, sampler.neighbourhoods = saved_mode, saved_nb
         if saved_par is not None:
             net.two_streams = saved_par
         for name, fn in installed:
@@ -206,6 +206,58 @@ def step_kernel_table(sampler, reps=3):
         row[2] += fl
         row[3] += by
     return table
+
+
+def executed_gflop_per_step(sampler, mode):
+    """GEMM work ONE step of form `mode` ('once' / 'whole') executes on the sampler's current x_t, in GFLOP: the sum over
+    the step's layer launches (pdr_fused_layer*, the pooled score convs, the thin coordinate tables, pdr_embed_linear)
+    of 2 rows Cin Cout with rows = 128 x the launch's tile count where it walks a tile subset (read back from the
+    device after the step), else all of its rows.  Not counted: the adds of pdr_gather_add (P Cout each), statistics,
+    pooling.  The REFERENCE's composition of the same step is 26.35 GFLOP per cloud: the difference is the
+    split first conv (per-point tables instead of a GEMM over the grouped tensor) and, for 'once', the neighbourhoods
+    evaluated once."""
+    from point_diffusion_refinement_amd.pointnet2 import fused_network as FN
+    lib = _lib.load()
+    calls, plans = [], {}
+    init = FN.Dedup.__init__
+
+    def rec_plan(self, *a, **k):
+        init(self, *a, **k)
+        plans[self.n_tiles.data_ptr()] = self.n_tiles
+    installed = []
+
+    def hook(name, fn, P_i, Cin_i, Cout_i):
+        def wrapped(*args):
+            li = args[0]._obj if hasattr(args[0], "_obj") else None
+            ptr = int(li.n_tiles or 0) if (li is not None and li.tile_list) else 0
+            calls.append((int(args[P_i]), int(args[Cin_i]), int(args[Cout_i]), ptr))
+            return fn(*args)
+        setattr(lib, name, wrapped)
+        installed.append((name, fn))
+    saved_mode = sampler._mode
+    FN.Dedup.__init__ = rec_plan
+    try:
+        for name, idx in (("pdr_fused_layer", (1, 2, 6)), ("pdr_fused_layer_f16x3", (1, 2, 6)),
+                          ("pdr_fused_layer_pool", (1, 2, 6)), ("pdr_fused_layer_pool_f16x3", (1, 2, 6)),
+                          ("pdr_embed_linear", (8, 9, 10))):
+            hook(name, getattr(lib, name), *idx)
+        sampler._mode = mode
+        state = [v.clone() for v in (sampler._x, sampler._t, sampler._ts, sampler._rng, sampler._probe)]
+        with torch.no_grad():
+            sampler._step()
+        torch.cuda.synchronize()
+        for v, w in zip((sampler._x, sampler._t, sampler._ts, sampler._rng, sampler._probe), state):
+            v.copy_(w)
+    finally:
+        FN.Dedup.__init__ = init
+        sampler._mode = saved_mode
+        for name, fn in installed:
+            setattr(lib, name, fn)
+    total = 0.0
+    for P, Cin, Cout, ptr in calls:
+        rows = 128 * int(plans[ptr]) if ptr else P
+        total += 2.0 * rows * Cin * Cout
+    return total / 1e9
 
 
 def _roof(flops, byt, ms, symbol, kind="mfma"):

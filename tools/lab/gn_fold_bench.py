@@ -13,7 +13,7 @@ for tpb, C in [(512, 32), (256, 64), (128, 128), (64, 128), (16, 256), (4, 512),
 
     def call():
         _lib.check(lib.pdr_gn_fold(part.data_ptr(), C, tpb, C, 1.0, None, 0, 0, 0, 1.0, B, C, 32, float(tpb * 128), 1e-5,
-                                   gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                   gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, 0, None, 0,
                                    torch.cuda.current_stream().cuda_stream), "fold")
     for _ in range(5):
         call()

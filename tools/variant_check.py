@@ -25,8 +25,18 @@ def main():
     with torch.no_grad():
         first = fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
         cached = fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True)
+        # a MIXED neighbourhood plan (x_t = q_sample(torus, 75): 30-90 % of the tiles walked): the variants of the
+        # deduplicated evaluation differ only where walked and skipped tiles sit side by side
+        from point_diffusion_refinement_amd.pointnet2 import util
+        from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG, q_sample, synthetic_surface_batch
+        x0, cond2, label2 = synthetic_surface_batch(2, seed=3, device=dev)
+        xm = q_sample(x0, 75, util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG), seed=3)
+        fused.reset_cond_features()
+        t75 = torch.full((2,), 75.0, device=dev)
+        fused(xm, cond2, ts=t75, label=label2, use_retained_condition_feature=True)
+        mixed = fused(xm * 0.98, cond2, ts=t75 - 1, label=label2, use_retained_condition_feature=True)
     torch.cuda.synchronize()
-    torch.save({"first": first.cpu(), "cached": cached.cpu()}, sys.argv[1])
+    torch.save({"first": first.cpu(), "cached": cached.cpu(), "mixed": mixed.cpu()}, sys.argv[1])
 
 
 if __name__ == "__main__":
