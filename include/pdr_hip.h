@@ -403,7 +403,8 @@ int pdr_dedup_plan(const int *idx, const int *counts, int B, int m, int K, int *
  * tile_valid, tile_list, n_tiles as pdr_dedup_plan; nvalid (2 B ints): [b] = valid tiles of cloud b -- with sorted
  * queries its FIRST nvalid[b] tiles --, [B + b] = nvalid[b] * (128 / K) = the first query of its skipped tiles
  * (pdr_layer_in_t.wrow0 of the per-query launches, pdr_gn_fold's nvalid); probe_acc (NULL or 2 ints, accumulated with
- * atomics): [0] += sum_b nvalid[b], [1] += B m K / 128.  B <= 1024, idx / idx_s 16-byte aligned. */
+ * atomics): [0] += sum_b nvalid[b], [1] += B m K / 128.  B <= 1024, m <= 4096 (PDR_EUNSUPPORTED beyond: the six
+ * launches it replaces), idx / idx_s 16-byte aligned. */
 int pdr_dedup_prepare(const int *idx, const int *counts, const float *xyz, int B, int m, int K, int *perm, int *inv,
                       int *perm_rows, int *idx_s, int *counts_s, float *xyz_s, int *idx0, float *row_w,
                       unsigned char *tile_valid, int *tile_list, int *n_tiles, int *nvalid, int *probe_acc,

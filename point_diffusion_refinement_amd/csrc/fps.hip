@@ -323,6 +323,168 @@ int launch_wave(const float* xyz, int B, int N, int m, int R, int Rbits, int Q, 
   return pdr::check_launch();
 }
 
+// ---- the resident kernel, instruction-lean (round 5) ------------------------------------------------------------
+// With one wave per SIMD a round is bound by the NUMBER of VALU instructions it issues, not by their latency alone:
+// the disassembly of fps_resident_kernel<256, 8> holds ~155 per round (72 for the eight distance updates incl. a
+// canonicalising v_max in front of every v_min, 24 for the in-lane arg-max, 47 for the 64-bit DPP arg-max -- two
+// v_mov_dpp, a 64-bit compare and two selects per step --, a dozen for the exchange) against 1,150 cycles measured.
+// fps_wave_kernel above trimmed the updates but pays an integer division per round to turn its tie rank back into a
+// point index, and ended up with as many instructions (532 vs 490 us).  This form keeps the resident kernel's
+// (distance bits, tie key | index) key -- no division -- and removes the rest:
+//   * the cloud lives in LDS as float4: one ds_read_b128 for the last pick instead of an address computation and
+//     three ds_read_b32;
+//   * distance updates on packed fp32 (two points per v_pk_add / v_pk_mul / v_pk_fma: each half IEEE-exact, the same
+//     SUM3 tree -> the same bits), v_min_f32 spelled directly: 32 instructions for eight points instead of 72;
+//   * the wave arg-max as two 32-bit reductions whose DPP shift is an operand modifier of the v_max_u32 itself (one
+//     instruction per step): the value (non-negative floats order like their bit patterns), then the key among the
+//     lanes that hold it: 12 + 6 instructions instead of 47.
+// Same picks as fps_resident_kernel for every input (tests/test_ops_gpu.py::test_fps_index_exact runs both:
+// PDR_FPS_LEAN=0 selects the old kernel).
+__device__ __forceinline__ unsigned fps_wave_max_u32(unsigned v) {
+  // lanes without a DPP source are disabled for that step and keep their own value; lane 63 ends with the maximum.
+  // (two wait states between a VALU write of a register and a DPP read of it: the assembler does not insert them)
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void fps_lean_kernel(const float* __restrict__ xyz, int N, int m, int R, int Rbits,
+                                                     int Q, int* __restrict__ idxs) {
+  static_assert(PPT % 2 == 0, "points are updated in pairs");
+  constexpr int W = T / 64;
+  extern __shared__ __attribute__((aligned(16))) float4 lean_cloud[];
+  __shared__ unsigned long long slots[2][W > 1 ? W : 1];   // per-wave key of a round, two parities
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* p = xyz + static_cast<size_t>(b) * N * 3;
+  int* out = idxs + static_cast<size_t>(b) * m;
+  for (int i = tid; i < N; i += T) lean_cloud[i] = make_float4(p[i * 3 + 0], p[i * 3 + 1], p[i * 3 + 2], 0.0f);
+
+  float sx[PPT], sy[PPT], sz[PPT], st[PPT];
+  unsigned low[PPT];  // (0xFFFF - tierank) << 16 | k ; larger = preferred
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * T;
+    if (k < N) {
+      sx[i] = p[k * 3 + 0];
+      sy[i] = p[k * 3 + 1];
+      sz[i] = p[k * 3 + 2];
+      const float mag = PDR_SUM3(sx[i], sy[i], sz[i]);
+      // reference: `if (mag <= 1e-3) continue;` -- float promoted to double
+      st[i] = (static_cast<double>(mag) <= 1e-3) ? -1.0f : 1e10f;
+      const unsigned rank = pdr::bitrev(static_cast<unsigned>(k % R), Rbits) * Q + k / R;
+      low[i] = ((0xFFFFu - rank) << 16) | static_cast<unsigned>(k);
+    } else {
+      sx[i] = sy[i] = sz[i] = 0.0f;
+      st[i] = -1.0f;  // padding: never selectable, never updated upward
+      low[i] = 0u;
+    }
+  }
+  // this thread's points by descending `low` (= ascending tie rank): "first strictly greater wins" inside the thread
+  // is then the reference's order
+#pragma unroll
+  for (int a = 0; a < PPT - 1; ++a) {
+#pragma unroll
+    for (int c = 0; c < PPT - 1 - a; ++c) {
+      if (low[c] < low[c + 1]) {
+        float t;
+        unsigned u;
+        t = sx[c]; sx[c] = sx[c + 1]; sx[c + 1] = t;
+        t = sy[c]; sy[c] = sy[c + 1]; sy[c + 1] = t;
+        t = sz[c]; sz[c] = sz[c + 1]; sz[c + 1] = t;
+        t = st[c]; st[c] = st[c + 1]; st[c + 1] = t;
+        u = low[c]; low[c] = low[c + 1]; low[c + 1] = u;
+      }
+    }
+  }
+  fps_f2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], tmp[PPT / 2];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    px[i >> 1][i & 1] = sx[i];
+    py[i >> 1][i & 1] = sy[i];
+    pz[i >> 1][i & 1] = sz[i];
+    tmp[i >> 1][i & 1] = st[i];
+  }
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float4 c = lean_cloud[old];
+    constexpr int G = PPT / 2;
+    fps_f2 dx[G], dy[G], dz[G], d[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) dy[g] = py[g] - c.y;
+#pragma unroll
+    for (int g = 0; g < G; ++g) dx[g] = px[g] - c.x;
+#pragma unroll
+    for (int g = 0; g < G; ++g) d[g] = dy[g] * dy[g];          // PDR_SUM3: fma(c, c, fma(a, a, b * b))
+#pragma unroll
+    for (int g = 0; g < G; ++g) dz[g] = pz[g] - c.z;
+#pragma unroll
+    for (int g = 0; g < G; ++g) d[g] = __builtin_elementwise_fma(dx[g], dx[g], d[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) d[g] = __builtin_elementwise_fma(dz[g], dz[g], d[g]);
+    float best = -1.0f;
+    unsigned bestlow = 0u;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      fps_f2 r;
+      asm("v_min_f32 %0, %1, %2" : "=v"(r[0]) : "v"(d[g][0]), "v"(tmp[g][0]));
+      asm("v_min_f32 %0, %1, %2" : "=v"(r[1]) : "v"(d[g][1]), "v"(tmp[g][1]));
+      tmp[g] = r;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool gt = r[e] > best;
+        best = gt ? r[e] : best;
+        bestlow = gt ? low[2 * g + e] : bestlow;
+      }
+    }
+    // best >= 0 -> monotone uint bits; "no candidate" (-1) -> 0
+    const unsigned vb = best < 0.0f ? 0u : __float_as_uint(best);
+    const unsigned vmax = fps_wave_max_u32(vb);                 // uniform
+    // (a candidate at distance +0.0 has value bits 0 like "no candidate", but keeps its key)
+    const unsigned cand = (vb == vmax && !(best < 0.0f)) ? bestlow : 0u;
+    unsigned wlow = fps_wave_max_u32(cand);
+    unsigned long long key = pdr::u64_from(vmax, wlow);
+    if constexpr (W > 1) {
+      unsigned long long* sl = slots[j & 1];
+      if ((tid & 63) == 0) sl[tid >> 6] = key;
+      __syncthreads();
+      unsigned long long r = sl[0];
+#pragma unroll
+      for (int w = 1; w < W; ++w) {
+        const unsigned long long o = sl[w];
+        r = o > r ? o : r;
+      }
+      key = r;
+    }
+    old = static_cast<int>(key & 0xFFFFull);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+template <int T, int PPT>
+int launch_lean(const float* xyz, int B, int N, int m, int R, int Rbits, int Q, int* idx, hipStream_t s) {
+  hipLaunchKernelGGL((fps_lean_kernel<T, PPT>), dim3(B), dim3(T), static_cast<size_t>(N) * sizeof(float4), s, xyz, N, m,
+                     R, Rbits, Q, idx);
+  return pdr::check_launch();
+}
+
 // Streaming fallback for N > kMaxResidentN: same ordering rule, running distances
 // in the caller's (B,N) temp (reference sampling.cpp:74-76), two-stage (value,
 // rank) arg-max.  Not on the BASELINE hot path; kept simple.
@@ -466,27 +628,24 @@ extern "C" int pdr_furthest_point_sampling(const float* xyz, int B, int N, int m
     if (slots <= 2048) return launch_wave<256, 8>(xyz, B, N, m, R, Rbits, Q, idx, s);
     return launch_wave<256, 16>(xyz, B, N, m, R, Rbits, Q, idx, s);
   }
+  // instruction-lean resident kernel (fps_lean_kernel): clouds whose float4 image fits the 64 KiB a launch gets without
+  // raising the dynamic LDS limit, an even number of points per thread.  PDR_FPS_LEAN=0: the round-1 resident kernel.
+  static const bool lean = []() {
+    const char* e = getenv("PDR_FPS_LEAN");
+    return !(e && e[0] == '0');
+  }();
+  if (lean && N > 128 && static_cast<size_t>(N) * sizeof(float4) + 256 <= 64 * 1024) {
+    if (N <= 512) return launch_lean<256, 2>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (N <= 1024) return launch_lean<256, 4>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (N <= 2048) return launch_lean<256, 8>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    if (N <= 3072) return launch_lean<256, 12>(xyz, B, N, m, R, Rbits, Q, idx, s);
+    return launch_lean<256, 16>(xyz, B, N, m, R, Rbits, Q, idx, s);
+  }
   static_assert(kMaxResidentN >= 12288, "resident path must cover the LDS-resident range");
 #define PDR_FPS_CASE(T, PPT) \
   if (N <= (T) * (PPT)) return launch_resident<T, PPT>(xyz, B, N, m, R, Rbits, Q, idx, s)
-  // PDR_FPS_THREADS (process-wide, read once; lab A/B, round 5): 512 / 1024 threads per cloud for N <= 4096 -- fewer
-  // points per thread (a shorter update chain per round) against a wider exchange (8 / 16 wave entries per round)
-  static const int fps_threads = []() {
-    const char* e = getenv("PDR_FPS_THREADS");
-    const int v = e ? atoi(e) : 256;
-    return (v == 512 || v == 1024) ? v : 256;
-  }();
-  if (fps_threads == 512 && N <= 4096) {
-    PDR_FPS_CASE(512, 1);
-    PDR_FPS_CASE(512, 2);
-    PDR_FPS_CASE(512, 4);
-    PDR_FPS_CASE(512, 8);
-  }
-  if (fps_threads == 1024 && N <= 4096) {
-    PDR_FPS_CASE(1024, 1);
-    PDR_FPS_CASE(1024, 2);
-    PDR_FPS_CASE(1024, 4);
-  }
+  // (512 / 1024 threads per cloud -- fewer points per thread against a wider exchange --, round 5, us per call at B = 32:
+  // 2048->1024 492 / 525 / 885, 1024->256 105 / 124 / 215 for 256 / 512 / 1024 threads: not taken)
   PDR_FPS_CASE(64, 1);
   PDR_FPS_CASE(64, 2);
   PDR_FPS_CASE(256, 1);

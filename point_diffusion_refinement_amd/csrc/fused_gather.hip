@@ -809,6 +809,7 @@ extern "C" int pdr_dedup_plan(const int* idx, const int* counts, int B, int m, i
 //       weights (K behind the cloud's valid tiles, else 0);
 //   (4) tile flags, the ascending tile list, per-cloud [nv | first weighted query], the probe counters.
 constexpr int kMaxPrepareClouds = 1024;
+constexpr int kMaxPrepareQueries = 4096;   // a cloud's permutation lives in LDS (16 KB)
 
 __global__ __launch_bounds__(1024) void dedup_prepare_kernel(
     const int* __restrict__ idx, const int* __restrict__ counts, const float* __restrict__ xyz, int m, int K, int nB,
@@ -817,22 +818,41 @@ __global__ __launch_bounds__(1024) void dedup_prepare_kernel(
     unsigned char* __restrict__ tile_valid, int* __restrict__ tile_list, int* __restrict__ n_tiles,
     int* __restrict__ nvalid, int* __restrict__ probe_acc) {
   __shared__ int nreal_s[kMaxPrepareClouds];
+  __shared__ int perm_s[kMaxPrepareQueries];
   __shared__ int wtot[16];
   __shared__ int base_s, prefix_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int qpt = 128 / K, tpb = m / qpt;
-  for (int i = tid; i <= b; i += 1024) nreal_s[i] = 0;
   if (tid == 0) base_s = 0;
-  __syncthreads();
-  // (1) (loads of different clouds are independent: the compiler keeps several in flight)
-  for (int bb = 0; bb <= b; ++bb) {
+  // (1) one WAVE per cloud 0 .. b (waves take clouds wave, wave + 16, ...): every lane's loads of a cloud are
+  // independent and issued together -- a 16-byte load per 4 counts where the rows allow it
+  const bool vec = (m & 3) == 0 && (reinterpret_cast<uintptr_t>(counts) & 15) == 0;   // uniform
+  for (int bb = wave; bb <= b; bb += 16) {
     const int* cb = counts + static_cast<long>(bb) * m;
     int c = 0;
-    for (int i = tid; i < m; i += 1024) c += cb[i] > 1 ? 1 : 0;
+    if (vec) {
+      const int4* c4 = reinterpret_cast<const int4*>(cb);
+      const int n4 = m >> 2;
+      for (int i0 = 0; i0 < n4; i0 += 64 * 8) {
+        int4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 64 * u + lane;
+          v[u] = c4[i < n4 ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = i0 + 64 * u + lane < n4;
+          c += ok ? (v[u].x > 1) + (v[u].y > 1) + (v[u].z > 1) + (v[u].w > 1) : 0;
+        }
+      }
+    } else {
+      for (int i = lane; i < m; i += 64) c += cb[i] > 1 ? 1 : 0;
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-    if (lane == 0 && c) atomicAdd(&nreal_s[bb], c);
+    if (lane == 0) nreal_s[bb] = c;
   }
   __syncthreads();
   if (tid == 0) {
@@ -862,6 +882,7 @@ __global__ __launch_bounds__(1024) void dedup_prepare_kernel(
       const int base = base_s;
       if (take) {
         const int j = base + woff + before;
+        perm_s[j] = i;
         pb[j] = i;
         ib[i] = j;
         if (perm_rows) perm_rows[static_cast<long>(b) * m + j] = b * m + i;
@@ -871,26 +892,37 @@ __global__ __launch_bounds__(1024) void dedup_prepare_kernel(
       __syncthreads();
     }
   }
-  // (the workgroup's own perm writes are visible to it behind the barrier above)
-  // (3) per-query rows in sorted order
+  // (3) per-query rows in sorted order (the permutation comes from LDS: no global round trip in front of every row)
   for (int j = tid; j < m; j += 1024) {
-    const int src = pb[j];
+    const int src = perm_s[j];
     const long qs = static_cast<long>(b) * m + src, qd = static_cast<long>(b) * m + j;
     counts_s[qd] = cb[src];
     idx0[qd] = idx[qs * K];
     row_w[qd] = j >= q0 ? static_cast<float>(K) : 0.0f;
     if (xyz) {
-      xyz_s[qd * 3 + 0] = xyz[qs * 3 + 0];
-      xyz_s[qd * 3 + 1] = xyz[qs * 3 + 1];
-      xyz_s[qd * 3 + 2] = xyz[qs * 3 + 2];
+      const float x = xyz[qs * 3 + 0], y = xyz[qs * 3 + 1], z = xyz[qs * 3 + 2];
+      xyz_s[qd * 3 + 0] = x;
+      xyz_s[qd * 3 + 1] = y;
+      xyz_s[qd * 3 + 2] = z;
     }
   }
-  const int k4 = K / 4;                               // 16-byte pieces per index row (K in {8, 16, 32})
-  for (int e = tid; e < m * k4; e += 1024) {
-    const int j = e / k4, part = e - j * k4;
-    const int src = pb[j];
-    const int4 v = *reinterpret_cast<const int4*>(idx + (static_cast<long>(b) * m + src) * K + 4 * part);
-    *reinterpret_cast<int4*>(idx_s + (static_cast<long>(b) * m + j) * K + 4 * part) = v;
+  // index rows as 16-byte pieces, four in flight per thread
+  const int k4 = K / 4, ksh4 = __builtin_ctz(k4);     // (K in {8, 16, 32}: 2, 4 or 8 pieces per row)
+  const int npiece = m * k4;
+  const int4* src4 = reinterpret_cast<const int4*>(idx + static_cast<long>(b) * m * K);
+  int4* dst4 = reinterpret_cast<int4*>(idx_s + static_cast<long>(b) * m * K);
+  for (int e0 = 0; e0 < npiece; e0 += 4096) {
+    int4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + 1024 * u + tid, npiece - 1);
+      v[u] = src4[(perm_s[e >> ksh4] << ksh4) + (e & (k4 - 1))];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + 1024 * u + tid;
+      if (e < npiece) dst4[e] = v[u];
+    }
   }
   // (4) tiles
   const int prefix = prefix_s;
@@ -948,7 +980,7 @@ extern "C" int pdr_dedup_prepare(const int* idx, const int* counts, const float*
     return PDR_EINVAL;
   if (!(K == 8 || K == 16 || K == 32) || (static_cast<long>(m) * K) % 128 != 0) return PDR_EINVAL;
   if (static_cast<long>(B) * m * K >= (1L << 31)) return PDR_EINVAL;
-  if (B > kMaxPrepareClouds) return PDR_EUNSUPPORTED;
+  if (B > kMaxPrepareClouds || m > kMaxPrepareQueries) return PDR_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(idx_s)) % 16 != 0) return PDR_EINVAL;
   if (B == 0) return PDR_OK;
   hipLaunchKernelGGL(dedup_prepare_kernel, dim3(B), dim3(1024), 0, pdr::as_stream(stream), idx, counts, xyz, m, K, B,

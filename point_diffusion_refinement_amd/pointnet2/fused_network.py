@@ -70,8 +70,8 @@ USE_VIRTUAL_KNN = True
 # (9.35 ms gathering only the 32-channel residuals, 9.24 up to 64, 9.20 all of them); kNN blocks: GATHER_RES_KNN.
 GATHER_RES = 4096
 GATHER_RES_KNN = True
-# Geometry prepass: one event per level instead of one after the whole chain (-1.8 % step time at B = 32)
-LEVEL_EVENTS = True
+# (Geometry: one event per level instead of one after the whole chain, -1.8 % step time at B = 32 in round 3; the
+# one-event form is gone since round 5 -- its variant run found the unordered cross-stream read documented at xyz4().)
 # Step-embedding chain as three pdr_embed_linear launches instead of ~12 torch / hipBLASLt ones (False: torch chain)
 NATIVE_EMBED = True
 # ... and, inside a sampler's loop, not even those: the chain depends on t only, so the samplers evaluate it for all T
@@ -302,7 +302,7 @@ class SortedQueries:
         self.inv = torch.empty((B, m), dtype=torch.int32, device=dev)
         self.perm_rows = torch.empty((B, m), dtype=torch.int32, device=dev)     # b m + perm: rows of a (B m)-row tensor
         self.plan = None
-        if FUSED_PLAN and K in (8, 16, 32) and (m * K) % 128 == 0 and B <= 1024:
+        if FUSED_PLAN and K in (8, 16, 32) and (m * K) % 128 == 0 and B <= 1024 and m <= 4096:
             new_xyz = new_xyz.contiguous()
             self.idx = torch.empty_like(idx)
             self.counts = torch.empty_like(counts)
@@ -407,7 +407,12 @@ _XYZ4 = {}
 def xyz4(t):
     """(B, n, C) channel-last rows padded to a multiple of 4 floats (cached per forward): as a C-wide segment
     with a 16-byte-aligned leading dimension they qualify for the float4-staged kernels; ld = 3 (coordinates)
-    or 35 would force the scalar-load path.  Returns the padded tensor (last dim = ld)."""
+    or 35 would force the scalar-load path.  Returns the padded tensor (last dim = ld).
+    The cache is shared by the streams of a forward: an entry remembers the stream that produced it and an event
+    behind the pad launch, and a hit from ANOTHER stream waits for that event first (round 4 ordered such pairs by hand,
+    producing the copy before a fork or on the consumer's stream; the one pair nobody had ordered -- the first
+    feature-transfer block's in-block tables on the main stream against its decoder twin's on the geometry stream,
+    LEVEL_EVENTS = False -- read the copy before it was written: tests/test_fused_gpu.py, variant test, mixed input)."""
     if t.shape[-1] % 4 == 0:
         return t
     key = (t.data_ptr(), tuple(t.shape))
@@ -416,14 +421,23 @@ def xyz4(t):
         # the entry holds the SOURCE too: while it lives, the allocator cannot hand the source's address to
         # another same-shape tensor, so a key can never alias a different tensor within one forward
         C = t.shape[-1]
+        stream = ev = None
         if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
             padded = torch.empty(t.shape[:-1] + (_pad4(C),), dtype=torch.float32, device=t.device)
             _lib.check(_lib.load().pdr_pad_rows(t.data_ptr(), t.numel() // C, C, padded.data_ptr(), _pad4(C),
                                                 _stream()), "pad_rows")
         else:
             padded = torch.nn.functional.pad(t, (0, -C % 4)).contiguous()
-        hit = (t, padded)
+        if t.is_cuda:
+            cur = torch.cuda.current_stream(t.device)
+            stream, ev = cur.cuda_stream, torch.cuda.Event()
+            ev.record(cur)
+        hit = (t, padded, stream, ev)
         _XYZ4[key] = hit
+    elif hit[3] is not None:
+        cur = torch.cuda.current_stream(t.device)
+        if cur.cuda_stream != hit[2]:
+            cur.wait_event(hit[3])
     return hit[1]
 
 
@@ -462,6 +476,16 @@ class Conv:
 # geometry stream as soon as a level's coordinates exist, ahead of that level's event, instead of at the head of
 # their block on the main stream (8.615 / 8.601 / 8.623 vs 8.642 / 8.660 / 8.675 ms inside the blocks).
 SIDE_TABLES = True
+# The sampling chain (FPS + gather per level) on a stream of its own instead of in front of each level's groupings on the
+# geometry stream: same box, 60 back-to-back replays, 6.07 / 6.13 vs 6.16 / 6.16 ms per step.
+# (ISSUE ORDER, measured with it: a LONE replay of the step shows the main stream's first kernel 0.29 ms into the step --
+# the graph's nodes reach the hardware queues one after the other in creation order, the geometry stream's ~50 first --
+# and interleaving the launches by need (sampling 0, first neighbourhoods, first block, level-l groupings just ahead of
+# the blocks that wait for them, the hoisted decoder halves last) moved the first block from 0.43 to 0.26 ms and the
+# end of the step from 6.28 to 6.18 ms in that picture.  In a sampling LOOP the host submits step i + 1 while step i
+# runs, the head is not waiting for its own submission, and the interleaved order was SLOWER: 6.44 / 6.46 vs 6.07 / 6.13
+# ms per step (with the sampling chain on the geometry stream 6.81 / 6.83 vs 6.16).  Geometry first, as in round 4.)
+FPS_STREAM = True
 _PAR = {"stream": None}
 
 
@@ -550,6 +574,8 @@ def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial_ptr, relu_col0):
     """Try the f16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel)."""
     if _PRECISION[0] != "split_f16" or conv.Cin < SPLIT_MIN_CIN:
         return False
+    if torch.is_tensor(partial_ptr):                    # (callers may hand over the statistics tensor itself)
+        partial_ptr = partial_ptr.data_ptr()
     variant = lib.pdr_fused_layer_variant(act.rpb, conv.Cout)
     if variant not in SPLIT_VARIANTS:
         return False
@@ -1621,6 +1647,11 @@ class FusedCloudConditionNet:
             self._side = torch.cuda.Stream(device=next(self.net.parameters()).device)
         return self._side
 
+    def _fps_stream(self):
+        if getattr(self, "_fps", None) is None:
+            self._fps = torch.cuda.Stream(device=next(self.net.parameters()).device)
+        return self._fps
+
     def _aux_stream(self):
         if getattr(self, "_aux", None) is None:
             self._aux = torch.cuda.Stream(device=next(self.net.parameters()).device)
@@ -1824,105 +1855,81 @@ class FusedCloudConditionNet:
         enc_cl, dec_cl = self.enc_cl, self.dec_cl
         l_uvw = net.l_uvw
 
-        # ---- geometry prepass on a side stream -------------------------------------------------
-        # FPS chain, every ball query and every kNN search depend on coordinates only.  They are
-        # latency / VALU-bound and (FPS) occupy 32 of 256 CUs, so they run beside the GEMMs of the
-        # first feature-transfer block instead of in front of each consumer.  The encoder and decoder
-        # feature-transfer modules of one level query the SAME clouds with the same radius / nsample
-        # (shipped configs): that ball query is computed once and shared.
+        # ---- geometry on two side streams ------------------------------------------------------------------------
+        # The sampling chain (FPS + gather per level: a pure dependency chain on 32 of 256 CUs, 0.63 ms end to end), every
+        # ball query with its plan, and every kNN search depend on coordinates only.  They run beside the GEMMs of the
+        # blocks on streams of their own: `fps` carries the sampling chain from the step's first microsecond, `side` the
+        # groupings, each waiting only for ITS level's sampling (one event per level, both ways).  All of it -- and the
+        # hoisted decoder halves -- is issued ahead of the first block (FPS_STREAM above: the measured alternatives).
+        # The encoder and decoder feature-transfer modules of one level query the SAME clouds with the same radius /
+        # nsample (shipped configs): that ball query is computed once and shared.
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        # the 16-byte padded level-0 coordinates are read by both streams: produce them HERE, ordered before the fork
-        # (the cache would otherwise hand the main stream a copy the side stream is still writing)
-        xyz4(xyz)
+        fps_s = self._fps_stream() if FPS_STREAM else side
+        xyz4(xyz)                                   # (read by all three streams: produced ahead of the fork)
         side.wait_stream(main)
+        fps_s.wait_stream(main)
         nlev = len(self.sa)
-        l_xyz, sels, fm_neigh, sa_neigh, knn, tables = [xyz], [], {}, [], {}, {}
+        l_xyz, sels, fm_neigh, sa_neigh, knn, tables = [xyz], [], {}, [None] * nlev, {}, {}
+        ev_fps, ev_sa, ev_fm = [None] * nlev, [None] * nlev, {}
+        side_tables_on = SIDE_TABLES and USE_SPLIT_FIRST
 
         def fm_key(i, blk):
             return (i % (nlev + 1), blk.radius, blk.nsample)
 
-        ev_first = None
-        # (The first block's neighbourhoods on the MAIN stream, the geometry stream opening with the sampling chain that
-        # the first SA block now waits 0.14 ms for: 6.60 vs 6.46 ms.  Removed, as in round 3.)
-        with torch.cuda.stream(side):
-            mark("side:begin")
-            fm_neigh[fm_key(0, self.enc_map[0])] = self.enc_map[0].plan_ahead(self.enc_map[0].neighbours(l_uvw[0], xyz), xyz)
-            if SIDE_TABLES and LEVEL_EVENTS and self.enc_map[0].split is not None:
-                tables[id(self.enc_map[0])] = self.enc_map[0].side_tables(fm_neigh[fm_key(0, self.enc_map[0])], xyz, True)
-            mark("side:first_ball_query_done")
-            ev_first = torch.cuda.Event()
-            ev_first.record(side)
-            # Level by level, each with its own events: SA block i starts as soon as ITS sampling / grouping is
-            # known, the feature-transfer block of level i + 1 as soon as its ball query is.  (One event after the
-            # whole chain made the main stream sit idle from the end of the first feature-transfer block, 0.85 ms
-            # into the step, until the last ball query at 1.07 ms -- tools/lab/step_markers.py, untraced replay.)
-            ev_sa, ev_fm = [], {}
-            for i, sa in enumerate(self.sa):
-                sel = _ext.furthest_point_sampling(l_xyz[i], sa.npoint)
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            return ev
+
+        def sample_level(i):
+            """fps stream: level i -> i + 1 (FPS + row gather), its event."""
+            with torch.cuda.stream(fps_s):
+                sel = _ext.furthest_point_sampling(l_xyz[i], self.sa[i].npoint)
                 sels.append(sel)
                 l_xyz.append(gather_rows(l_xyz[i], sel))
-                sa_neigh.append(sa.plan_ahead(sa.neighbours(l_xyz[i], l_xyz[i + 1]), l_xyz[i + 1]))
-                if LEVEL_EVENTS:
-                    xyz4(l_xyz[i + 1])          # padded coordinates of the new level: produced before its event
-                    if SIDE_TABLES and sa.split is not None:
-                        tables[id(sa)] = sa.side_tables(sa_neigh[i], l_xyz[i + 1], False)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    ev_sa.append(ev)
-                    lv = i + 1
-                    for blk in ([self.enc_map[lv]] if lv < nlev else []) + [self.dec_map[lv]]:
-                        if fm_key(lv, blk) not in fm_neigh:
-                            fm_neigh[fm_key(lv, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[lv], l_xyz[lv]), l_xyz[lv])
-                        if SIDE_TABLES and blk.split is not None:
-                            tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(lv, blk)], l_xyz[lv], True)
-                    ev_fm[lv] = torch.cuda.Event()
-                    ev_fm[lv].record(side)
-            for i in range(nlev + 1):
-                for blk in ([self.enc_map[i]] if i < nlev else []) + [self.dec_map[i]]:
-                    if fm_key(i, blk) not in fm_neigh:
-                        fm_neigh[fm_key(i, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[i], l_xyz[i]), l_xyz[i])
-            mark("side:encoder_geometry_done")
-            ev_all = torch.cuda.Event()                 # everything the encoder needs
-            ev_all.record(side)
-            ev_tables = None
-            if SIDE_TABLES and USE_SPLIT_FIRST and LEVEL_EVENTS:
-                # per level above; here the rest: the level-0 decoder block and the feature-propagation blocks (used
-                # by the decoder, behind ev_knn)
-                if self.dec_map[0].split is not None:
-                    tables[id(self.dec_map[0])] = self.dec_map[0].side_tables(fm_neigh[fm_key(0, self.dec_map[0])],
-                                                                              l_xyz[0], True)
-                for i in range(-1, -(len(self.fp) + 1), -1):
-                    if self.fp[i].split is not None:
-                        tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
-            elif SIDE_TABLES and USE_SPLIT_FIRST:
-                # (a block's SplitFirstConv exists from its first evaluation on; the eager first step of a batch
-                # therefore computes the tables inline, every captured step here)
-                for i in range(nlev + 1):
-                    for blk in ([self.enc_map[i]] if 0 < i < nlev else []) + [self.dec_map[i]]:
-                        if blk.split is not None:
-                            tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(i, blk)], l_xyz[i], True)
-                for i, sa in enumerate(self.sa):
-                    if sa.split is not None:
-                        tables[id(sa)] = sa.side_tables(sa_neigh[i], l_xyz[i + 1], False)
-                for i in range(-1, -(len(self.fp) + 1), -1):
-                    if self.fp[i].split is not None:
-                        tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
-                ev_tables = torch.cuda.Event()
-                ev_tables.record(side)
-            for i in range(-1, -(len(self.fp) + 1), -1):
-                knn[i] = _ext.knn_group(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
-            mark("side:knn_done")
-            ev_knn = torch.cuda.Event()                 # the kNN searches are first used by the decoder
-            ev_knn.record(side)
+                ev_fps[i] = event(fps_s)
 
-        # ---- step embeddings, beside the running geometry stream.  (Issued ahead of the fork instead: 8.79 / 8.82 / 8.83
-        # vs 8.77 / 8.79 / 8.80 ms -- the FPS chain starts later; on the geometry stream behind the first ball query:
-        # 8.80 / 8.76 vs 8.73 / 8.73; DESIGN.md section 8.0.  Query-independent halves of the deep feature-transfer
-        # blocks ahead of time on a third stream: 12.22 / 11.72 vs 11.65 ms -- removed in round 4.)
+        def transfer_level(lv, tables_for):
+            """side stream: neighbourhoods + plan (+ per-query tables) of the feature-transfer blocks of level lv."""
+            with torch.cuda.stream(side):
+                for blk in ([self.enc_map[lv]] if lv < nlev else []) + [self.dec_map[lv]]:
+                    if fm_key(lv, blk) not in fm_neigh:
+                        fm_neigh[fm_key(lv, blk)] = blk.plan_ahead(blk.neighbours(l_uvw[lv], l_xyz[lv]), l_xyz[lv])
+                    if side_tables_on and blk.split is not None and blk in tables_for:
+                        tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(lv, blk)], l_xyz[lv], True)
+                ev_fm[lv] = event(side)
+
+        def group_level(i):
+            """side stream: SA block i's neighbourhoods + plan + tables (needs level i + 1 of the sampling chain)."""
+            sa = self.sa[i]
+            if not FPS_STREAM:
+                sample_level(i)                 # (one geometry stream: the sampling right in front of its consumers)
+            with torch.cuda.stream(side):
+                if FPS_STREAM:
+                    side.wait_event(ev_fps[i])
+                sa_neigh[i] = sa.plan_ahead(sa.neighbours(l_xyz[i], l_xyz[i + 1]), l_xyz[i + 1])
+                xyz4(l_xyz[i + 1])              # padded coordinates of the new level: produced before its event
+                if side_tables_on and sa.split is not None:
+                    tables[id(sa)] = sa.side_tables(sa_neigh[i], l_xyz[i + 1], False)
+                ev_sa[i] = event(side)
+
+        with torch.cuda.stream(fps_s):
+            mark("fps:begin")
+        if FPS_STREAM:
+            sample_level(0)
+        transfer_level(0, (self.enc_map[0],))
+        with torch.cuda.stream(side):
+            mark("side:first_ball_query_done")
+        if FPS_STREAM:
+            for i in range(1, nlev):
+                sample_level(i)
+
+        # ---- step embeddings (one row lookup inside a sampler's loop, else the three-launch chain)
         mark("main:before_embeddings", detail=True)
         self._embeddings(ts, label)
         mark("main:embeddings_done")
+        ev_emb = event(main)
 
         def transfer(blk, l, cl, query, V2=None):
             if id(blk) in prepared:
@@ -1932,45 +1939,71 @@ class FusedCloudConditionNet:
             return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
 
         prepared = {}
-        if AHEAD_DECODER_MAPS and USE_SPLIT_FIRST and self.two_streams:
-            ev_emb = torch.cuda.Event()
-            ev_emb.record(main)
+        hoist = AHEAD_DECODER_MAPS and USE_SPLIT_FIRST and self.two_streams
+        hoisted = [False]
+
+        def hoist_decoder_map(l):
+            """side stream: the query-independent half of the decoder's feature-transfer block of level l (first-conv
+            statistics, shared MLP, value conv: coordinates, static condition features and embeddings only)."""
+            blk = self.dec_map[l]
+            if not hoist or tables.get(id(blk)) is None:
+                # (no per-query tables made on the geometry stream: the block runs whole on the main stream)
+                return
             with torch.cuda.stream(side):
-                side.wait_event(ev_emb)                     # the blocks' MLPs add the step / condition embeddings
+                if not hoisted[0]:
+                    side.wait_event(ev_emb)                 # the blocks' MLPs add the step / condition embeddings
+                    hoisted[0] = True
                 saved_par, _PAR["stream"] = _PAR["stream"], None
-                for l in range(nlev, -1, -1):               # in the order the decoder will ask for them
-                    blk = self.dec_map[l]
-                    if tables.get(id(blk)) is None:
-                        # (no per-query tables made on this stream: the block would evaluate them -- and pad its
-                        # coordinates through the per-forward xyz4 cache -- on two unordered streams)
-                        continue
-                    prep = blk.prepare(l_uvw[l], dec_cl[l], l_xyz[l], bank, subset=False,
-                                       neigh=fm_neigh[fm_key(l, blk)], V2=tables.get(id(blk)))
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    prepared[id(blk)] = (prep, ev)
+                prep = blk.prepare(l_uvw[l], dec_cl[l], l_xyz[l], bank, subset=False,
+                                   neigh=fm_neigh[fm_key(l, blk)], V2=tables.get(id(blk)))
                 _PAR["stream"] = saved_par
+                prepared[id(blk)] = (prep, event(side))
+
+        def geometry_tail():
+            """side stream, behind the last level's groupings: the remaining per-query tables and the kNN searches (first
+            used by the decoder)."""
+            with torch.cuda.stream(side):
+                mark("side:encoder_geometry_done")
+                if side_tables_on:
+                    if self.dec_map[0].split is not None:
+                        tables[id(self.dec_map[0])] = self.dec_map[0].side_tables(fm_neigh[fm_key(0, self.dec_map[0])],
+                                                                                  l_xyz[0], True)
+                    for i in range(-1, -(len(self.fp) + 1), -1):
+                        if self.fp[i].split is not None:
+                            tables[id(self.fp[i])] = self.fp[i].split.query_tables(l_xyz[i - 1], has_v0=False)
+                for i in range(-1, -(len(self.fp) + 1), -1):
+                    knn[i] = _ext.knn_group(l_xyz[i - 1], l_xyz[i], self.fp[i].K)
+                mark("side:knn_done")
+                return event(side)
+
+        # every remaining geometry launch and every hoisted half ahead of the first block (see FPS_STREAM above for why
+        # not interleaved with the blocks)
+        for k in range(nlev):
+            group_level(k)
+            lv = k + 1
+            transfer_level(lv, (self.enc_map[lv],) if lv < nlev else (self.dec_map[lv],))
+        if side_tables_on:
+            # the decoder's transfer blocks of the inner levels share the encoder's neighbourhoods: their tables
+            with torch.cuda.stream(side):
+                for l in range(1, nlev):
+                    blk = self.dec_map[l]
+                    if blk.split is not None and id(blk) not in tables:
+                        tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(l, blk)], l_xyz[l], True)
+        ev_knn = geometry_tail()
+        for l in range(nlev, -1, -1):                       # in the order the decoder will ask for them
+            hoist_decoder_map(l)
 
         # ---- feature path ------------------------------------------------------------------------
-        if ev_first is not None:
-            main.wait_event(ev_first)
+        main.wait_event(ev_fm[0])
         mark("main:after_wait_first_ball_query")
         l_feat = [feat0]
         for i, sa in enumerate(self.sa):
-            if LEVEL_EVENTS and i > 0:
+            if i > 0:
                 main.wait_event(ev_fm[i])
             mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])))
             mark("main:enc_map%d_done" % i)
-            if LEVEL_EVENTS:
-                main.wait_event(ev_sa[i])
-                if i == 0 and ev_tables is not None:
-                    main.wait_event(ev_tables)
-                mark("main:after_wait_sa%d_geometry" % i)
-            elif i == 0:
-                main.wait_event(ev_all)
-                if ev_tables is not None:
-                    main.wait_event(ev_tables)
-                mark("main:after_wait_encoder_geometry")
+            main.wait_event(ev_sa[i])
+            mark("main:after_wait_sa%d_geometry" % i)
             sa_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
             centre = gather_rows(sa_in, sels[i])
             l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i],

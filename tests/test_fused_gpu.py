@@ -304,8 +304,8 @@ _VARIANTS = [
     ("residual_written", {"PDR_FUSED_OPTS": "GATHER_RES=0"}, False),
     ("residual_32", {"PDR_FUSED_OPTS": "GATHER_RES=32"}, False),
     ("residual_knn_written", {"PDR_FUSED_OPTS": "GATHER_RES_KNN=0"}, False),
-    ("one_geometry_event", {"PDR_FUSED_OPTS": "LEVEL_EVENTS=0"}, True),
     ("tables_in_blocks", {"PDR_FUSED_OPTS": "SIDE_TABLES=0"}, True),
+    ("sampling_on_the_geometry_stream", {"PDR_FUSED_OPTS": "FPS_STREAM=0"}, True),
     ("torch_embedding_chain", {"PDR_FUSED_OPTS": "NATIVE_EMBED=0"}, False),
     ("query_conv_unsplit", {"PDR_FUSED_OPTS": "SPLIT_QUERY_CONV=0"}, False),
     ("grouped_first_conv", {"PDR_FUSED_OPTS": "USE_SPLIT_FIRST=0"}, False),
@@ -1408,7 +1408,10 @@ def test_gather_add_tiles_twin_equals_the_three_launches(cuda):
         assert bool(torch.isnan(vb[:, :tpb][~valid]).all())             # skipped tiles: not written (nobody zeroes them)
         ta, tb = va[:, tpb:].double(), vb[:, tpb:].double()
         assert not bool(torch.isnan(tb).any())
-        assert float(((ta - tb).abs() / (ta.abs() + 1.0)).max()) < 2e-5
+        # (two fp32 summation orders of up to 128 weighted rows; judged against the size of the sums' terms: the second
+        # moment bounds both -- |sum w f| <= sum w f^2 + sum w)
+        scale = ta[..., 1:2].abs() + 32.0 * 128
+        assert float(((ta - tb).abs() / scale).max()) < 2e-6
 
 
 @pytest.mark.parametrize("rpb,Cin,Cout", [(2048, 32, 32), (1024, 64, 128), (256, 128, 128), (64, 256, 128), (16, 512, 512),

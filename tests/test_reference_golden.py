@@ -345,7 +345,9 @@ def test_full_ddpm_config_dense_and_mixed_neighbourhoods_match_reference(be):
         return
     for k, t in calls:
         be.net_close(out[k], g[k], "ddpm_full:dense_%s" % k, xt[t])
-    assert torch.equal(rec.xs[0], ref_xs[0])                               # the same restart point: same CPU noise
+    # the same restart point: same CPU noise; x^4 + Sigma[4] z itself is evaluated on the GPU here (one fp32 product and
+    # sum per coordinate: measured 1 ulp from the CPU's in places)
+    assert float((rec.xs[0] - ref_xs[0]).abs().max()) <= 1e-7
     cfg = ddpm_pointnet_config()
     _judge_trajectory(be, cfg, cond, "ddpm_full:dense_sampling:layer_by_layer", samp, rec.xs, ref_xs, g["out"])
     from point_diffusion_refinement_amd.pointnet2 import fused_network as FN

@@ -34,8 +34,12 @@ def main():
     R = 20
     rows = []
     torch.cuda.synchronize()
+    # MARK_BACK_TO_BACK=n: n replays queued without a synchronisation in between, the stamps of the LAST one read -- the
+    # steady state of a sampling loop, where the host submits step i + 1 while step i runs (a lone replay, the default,
+    # also shows how long the submission of the step's own nodes takes: the two pictures differ at the head of the step)
+    b2b = int(os.environ.get("MARK_BACK_TO_BACK", "1"))
     for _ in range(R):
-        sampler.advance(1)
+        sampler.advance(b2b)
         torch.cuda.synchronize()
         rows.append(buf[half:2 * half].cpu().numpy().astype("int64"))
     import numpy as np
@@ -43,7 +47,7 @@ def main():
     rel = (t - t[:, :1]) * 0.01                              # us after step:begin
     med = np.median(rel, axis=0)
     order = np.argsort(med, kind="stable") if not FN_DETAIL else np.arange(len(med))
-    out = {"batch": B, "replays": R, "precision": os.environ.get("MARK_PRECISION", "f32"),
+    out = {"batch": B, "replays": R, "back_to_back": b2b, "precision": os.environ.get("MARK_PRECISION", "f32"),
            "unit": "us after step:begin (median of replays; 100 MHz clock)",
            "marks": [{"name": names[i], "median_us": float(med[i]), "min_us": float(rel[:, i].min()),
                       "max_us": float(rel[:, i].max())} for i in order]}
