@@ -41,8 +41,8 @@ class GradientAllReduce:
             self._close(cur)
         self._where = {}
         for bi, (_, items) in enumerate(self.buckets):
-            for p, off, n in items:
-                self._where[p] = (bi, off, n)
+            for i, (p, off, n) in enumerate(items):
+                self._where[p] = (bi, off, n, i)
         self._pending = [len(items) for _, items in self.buckets]
         self._handles = []
         self._queued = False
@@ -66,9 +66,13 @@ class GradientAllReduce:
         self.buckets.append((flat, items))
 
     def _on_grad(self, p):
-        bi, off, n = self._where[p]
+        bi, off, n, i = self._where[p]
         flat, items = self.buckets[bi]
         flat.narrow(0, off, n).copy_(p.grad.reshape(-1))
+        # "this rank produced a gradient": the flag slot is set ON THE DEVICE (a fill launch, no host transfer inside
+        # the autograd hook: round 4 built the flags on the host and copied them in _launch -- a blocking copy from
+        # pageable memory per bucket that stalled backward exactly where the buckets exist to overlap it)
+        flat.narrow(0, flat.numel() - len(items) + i, 1).fill_(1)
         self._fired.add(p)
         self._pending[bi] -= 1
         # a complete bucket starts its ring transfer now -- in BUCKET ORDER (collectives are matched across
@@ -87,7 +91,7 @@ class GradientAllReduce:
             for (p, off, n), f in zip(items, fired):
                 if not f:                                      # (also covers a stale .grad of an earlier step)
                     flat.narrow(0, off, n).zero_()
-        flat.narrow(0, total, len(items)).copy_(torch.tensor(fired, dtype=flat.dtype))
+        # (the flag slots were zeroed by the previous synchronize / at construction and set by _on_grad)
         self._handles.append((bi, dist.all_reduce(flat, group=self.group, async_op=True)))
         self._next = bi + 1
 
@@ -98,12 +102,21 @@ class GradientAllReduce:
         # issuing different numbers of collectives hang).  Parameters without a gradient contribute zeros.
         while self._next < len(self.buckets):
             self._launch(self._next)
-        for bi, h in self._handles:
+        for _, h in self._handles:
             h.wait()
+        # per parameter: how many ranks produced a gradient -- the flag slots of ALL buckets in ONE device-to-host
+        # transfer behind the waits (one .tolist() per bucket was one host synchronisation per bucket)
+        flags = torch.cat([self.buckets[bi][0].narrow(0, self.buckets[bi][0].numel() - len(self.buckets[bi][1]),
+                                                       len(self.buckets[bi][1])) for bi, _ in self._handles]).tolist() \
+            if self._handles else []
+        pos = 0
+        for bi, _ in self._handles:
             flat, items = self.buckets[bi]
             total = flat.numel() - len(items)
-            used = flat.narrow(0, total, len(items)).tolist()   # per parameter: how many ranks produced a gradient
+            used = flags[pos:pos + len(items)]
+            pos += len(items)
             flat.narrow(0, 0, total).div_(self.world)
+            flat.narrow(0, total, len(items)).zero_()          # flag slots ready for the next backward
             for (p, off, n), cnt in zip(items, used):
                 avg = flat.narrow(0, off, n).view_as(p)
                 if p.grad is not None and p in self._fired:

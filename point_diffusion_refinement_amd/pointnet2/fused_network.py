@@ -121,6 +121,10 @@ FUSED_PATCH = True
 # (The same half of the ENCODER's blocks of levels >= 1 on a fourth stream, each as soon as its level's geometry exists:
 # 7.07 vs 6.46 ms -- it runs beside the sampling chain and the SA blocks that everything else waits for.  Removed.)
 AHEAD_DECODER_MAPS = True
+# ... the level-0 one of them on the MAIN stream, right behind the first feature-transfer block: in a sampling loop the
+# main stream then sits idle until the level-0 sampling is done (0.32 -> 0.57 ms: tools/lab/step_markers.py,
+# MARK_BACK_TO_BACK), and that half needs level-0 coordinates only.  Same box: 6.04 / 6.02 vs 6.09 / 6.10 ms per step.
+HOIST_LEVEL0_ON_MAIN = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -486,6 +490,9 @@ SIDE_TABLES = True
 # runs, the head is not waiting for its own submission, and the interleaved order was SLOWER: 6.44 / 6.46 vs 6.07 / 6.13
 # ms per step (with the sampling chain on the geometry stream 6.81 / 6.83 vs 6.16).  Geometry first, as in round 4.)
 FPS_STREAM = True
+# (The feature-propagation blocks' two halves on ONE stream -- VERDICT r4 item 3: their kernels fill the chip, the dominant
+# one takes 182 us inside the two-stream step against 145 us alone --: 6.07 / 6.06 vs 6.05 / 6.08 ms per step, same box:
+# what one kernel loses beside its neighbour the neighbour gains.  Not a switch.)
 _PAR = {"stream": None}
 
 
@@ -1557,9 +1564,20 @@ class FusedPnet2Stage:
         dev = g.device
         one = torch.ones((B, C1), device=dev) if f.scale is None else f.scale
         zero = torch.zeros((B, C1), device=dev)
-        # [f | g.expand(n)]: the second half = the same rows at scale 0 (finite values x 0 = 0) + the `add` row g
-        both = Act([(Y, 0, C1, ld, 1), (Y, 0, C1, ld, 1)], B * n, B, n,
-                   scale=torch.cat([one, zero], 1).contiguous(),
+        # [f | g.expand(n)]: the second half = rows of ZEROS + the `add` row g.  The zeros are a small buffer read as a
+        # neighbour-broadcast segment (one row per d positions, d = the largest power of two dividing both the cloud and
+        # the tile height); round 4 read Y a second time at scale 0, which turned an inf in Y into NaN where the
+        # reference's concatenation holds a finite g -- kept only for clouds no power of two > 1 divides
+        tm = _lib.load().pdr_fused_layer_tile_rows(n, self.s2[0][0].Cout)
+        d = 1
+        while d * 2 <= tm and n % (d * 2) == 0 and tm % (d * 2) == 0:
+            d *= 2
+        if d > 1 and C1 % 4 == 0:
+            second, s_second = (torch.zeros((B * n // d, C1), device=dev), 0, C1, C1, d), one
+        else:
+            second, s_second = (Y, 0, C1, ld, 1), zero
+        both = Act([(Y, 0, C1, ld, 1), second], B * n, B, n,
+                   scale=torch.cat([one, s_second], 1).contiguous(),
                    shift=torch.cat([zero if f.shift is None else f.shift, zero], 1).contiguous(),
                    add=torch.cat([zero, g], 1).contiguous(), add_ld=2 * C1, post_relu=f.post_relu)
         return act_colmax(self._mlp(both, self.s2, B, n))
@@ -1918,7 +1936,7 @@ class FusedCloudConditionNet:
             mark("fps:begin")
         if FPS_STREAM:
             sample_level(0)
-        transfer_level(0, (self.enc_map[0],))
+        transfer_level(0, (self.enc_map[0], self.dec_map[0]) if HOIST_LEVEL0_ON_MAIN else (self.enc_map[0],))
         with torch.cuda.stream(side):
             mark("side:first_ball_query_done")
         if FPS_STREAM:
@@ -1934,7 +1952,8 @@ class FusedCloudConditionNet:
         def transfer(blk, l, cl, query, V2=None):
             if id(blk) in prepared:
                 prep, ev = prepared[id(blk)]
-                main.wait_event(ev)
+                if ev is not None:
+                    main.wait_event(ev)
                 return blk.finish(prep, query)
             return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
 
@@ -1965,7 +1984,7 @@ class FusedCloudConditionNet:
             with torch.cuda.stream(side):
                 mark("side:encoder_geometry_done")
                 if side_tables_on:
-                    if self.dec_map[0].split is not None:
+                    if self.dec_map[0].split is not None and id(self.dec_map[0]) not in tables:
                         tables[id(self.dec_map[0])] = self.dec_map[0].side_tables(fm_neigh[fm_key(0, self.dec_map[0])],
                                                                                   l_xyz[0], True)
                     for i in range(-1, -(len(self.fp) + 1), -1):
@@ -1990,7 +2009,7 @@ class FusedCloudConditionNet:
                     if blk.split is not None and id(blk) not in tables:
                         tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(l, blk)], l_xyz[l], True)
         ev_knn = geometry_tail()
-        for l in range(nlev, -1, -1):                       # in the order the decoder will ask for them
+        for l in range(nlev, 0 if HOIST_LEVEL0_ON_MAIN else -1, -1):   # in the order the decoder will ask for them
             hoist_decoder_map(l)
 
         # ---- feature path ------------------------------------------------------------------------
@@ -2002,6 +2021,12 @@ class FusedCloudConditionNet:
                 main.wait_event(ev_fm[i])
             mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])))
             mark("main:enc_map%d_done" % i)
+            if i == 0 and HOIST_LEVEL0_ON_MAIN and hoist and tables.get(id(self.dec_map[0])) is not None:
+                saved_par, _PAR["stream"] = _PAR["stream"], None
+                prepared[id(self.dec_map[0])] = (self.dec_map[0].prepare(
+                    l_uvw[0], dec_cl[0], l_xyz[0], bank, subset=False, neigh=fm_neigh[fm_key(0, self.dec_map[0])],
+                    V2=tables.get(id(self.dec_map[0]))), None)
+                _PAR["stream"] = saved_par
             main.wait_event(ev_sa[i])
             mark("main:after_wait_sa%d_geometry" % i)
             sa_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)

@@ -318,6 +318,7 @@ _VARIANTS = [
     ("patch_rows_launch", {"PDR_FUSED_OPTS": "FUSED_PATCH=0"}, True),
     ("dedup_from_256_queries", {"PDR_FUSED_OPTS": "DEDUP_MIN_QUERIES=256"}, False),
     ("decoder_maps_in_place", {"PDR_FUSED_OPTS": "AHEAD_DECODER_MAPS=0"}, False),
+    ("level0_decoder_map_on_the_geometry_stream", {"PDR_FUSED_OPTS": "HOIST_LEVEL0_ON_MAIN=0"}, False),
 ]
 
 
