@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--precision", choices=("f32", "split_f16", "split_bf16"), default="f32",
                     help="arithmetic of the wide 1x1-conv GEMMs of the HEADLINE run (default exact fp32 MFMA); "
                          "split_bf16 = deprecated alias of split_f16 (the halves are f16 since round 3)")
+    ap.add_argument("--neighbourhoods", choices=("adaptive", "once", "whole"), default="adaptive",
+                    help="form of the captured step of the HEADLINE run: adaptive (the product default: per-step switch), "
+                         "once / whole = one form for every step (A/B and profiling)")
     ap.add_argument("--single-stream", action="store_true",
                     help="profiling: the two halves of every block on ONE stream, so that every kernel has the chip to "
                          "itself (tools/profile_round.sh's serial pass); never the headline")
@@ -364,7 +367,7 @@ def main():
     from point_diffusion_refinement_amd.pointnet2 import generation as G
     from point_diffusion_refinement_amd.pointnet2.configs import synthetic_batch
     sampler, net = build_sampler(device, not args.no_graph, fused=not args.unfused, precision=args.precision,
-                                 single_stream=args.single_stream)
+                                 single_stream=args.single_stream, neighbourhoods=args.neighbourhoods)
     B = args.batch
     # every rank draws ITS OWN shard of the synthetic partial clouds (seed offset by rank)
     x_T, cond, label = synthetic_batch(B, N_POINTS, M_COND, seed=rank, device=device)

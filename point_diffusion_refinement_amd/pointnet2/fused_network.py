@@ -1883,7 +1883,13 @@ class FusedCloudConditionNet:
         # nsample (shipped configs): that ball query is computed once and shared.
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        fps_s = self._fps_stream() if FPS_STREAM else side
+        # (both placements pay only while the blocks' launches are small -- one-point neighbourhoods evaluated once; with
+        # every neighbourhood evaluated the main stream has no idle window and the sampling chain competes with full
+        # kernels: same box, whole form, 9.33 / 9.34 ms per step with both, 8.78 without the level-0 hoist on the main
+        # stream, 8.70 / 8.72 without either)
+        fps_on = FPS_STREAM and _dedup_on()
+        hoist0_main = HOIST_LEVEL0_ON_MAIN and _dedup_on()
+        fps_s = self._fps_stream() if fps_on else side
         xyz4(xyz)                                   # (read by all three streams: produced ahead of the fork)
         side.wait_stream(main)
         fps_s.wait_stream(main)
@@ -1921,10 +1927,10 @@ class FusedCloudConditionNet:
         def group_level(i):
             """side stream: SA block i's neighbourhoods + plan + tables (needs level i + 1 of the sampling chain)."""
             sa = self.sa[i]
-            if not FPS_STREAM:
+            if not fps_on:
                 sample_level(i)                 # (one geometry stream: the sampling right in front of its consumers)
             with torch.cuda.stream(side):
-                if FPS_STREAM:
+                if fps_on:
                     side.wait_event(ev_fps[i])
                 sa_neigh[i] = sa.plan_ahead(sa.neighbours(l_xyz[i], l_xyz[i + 1]), l_xyz[i + 1])
                 xyz4(l_xyz[i + 1])              # padded coordinates of the new level: produced before its event
@@ -1934,12 +1940,12 @@ class FusedCloudConditionNet:
 
         with torch.cuda.stream(fps_s):
             mark("fps:begin")
-        if FPS_STREAM:
+        if fps_on:
             sample_level(0)
-        transfer_level(0, (self.enc_map[0], self.dec_map[0]) if HOIST_LEVEL0_ON_MAIN else (self.enc_map[0],))
+        transfer_level(0, (self.enc_map[0], self.dec_map[0]) if hoist0_main else (self.enc_map[0],))
         with torch.cuda.stream(side):
             mark("side:first_ball_query_done")
-        if FPS_STREAM:
+        if fps_on:
             for i in range(1, nlev):
                 sample_level(i)
 
@@ -2009,7 +2015,7 @@ class FusedCloudConditionNet:
                     if blk.split is not None and id(blk) not in tables:
                         tables[id(blk)] = blk.side_tables(fm_neigh[fm_key(l, blk)], l_xyz[l], True)
         ev_knn = geometry_tail()
-        for l in range(nlev, 0 if HOIST_LEVEL0_ON_MAIN else -1, -1):   # in the order the decoder will ask for them
+        for l in range(nlev, 0 if hoist0_main else -1, -1):   # in the order the decoder will ask for them
             hoist_decoder_map(l)
 
         # ---- feature path ------------------------------------------------------------------------
@@ -2021,7 +2027,7 @@ class FusedCloudConditionNet:
                 main.wait_event(ev_fm[i])
             mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])))
             mark("main:enc_map%d_done" % i)
-            if i == 0 and HOIST_LEVEL0_ON_MAIN and hoist and tables.get(id(self.dec_map[0])) is not None:
+            if i == 0 and hoist0_main and hoist and tables.get(id(self.dec_map[0])) is not None:
                 saved_par, _PAR["stream"] = _PAR["stream"], None
                 prepared[id(self.dec_map[0])] = (self.dec_map[0].prepare(
                     l_uvw[0], dec_cl[0], l_xyz[0], bank, subset=False, neigh=fm_neigh[fm_key(0, self.dec_map[0])],
