@@ -35,9 +35,9 @@ import torch
 class GraphedReverseSampler:
     # neighbourhoods='adaptive': walked share (tiles walked / tiles of the deduplicable blocks) above which the step
     # with every neighbourhood evaluated is replayed.  bench.py's `trajectory` leg times both forms over the share.
-    # (MI355X, B = 32, x_t = q_sample(torus, t): the two forms cross at a walked share of 0.65 -- 0.53: 8.53 vs 9.01 ms,
-    # 0.68: 9.12 vs 9.02, 0.96: 9.93 vs 9.06)
-    WHOLE_ABOVE = 0.62
+    # (MI355X, B = 32, x_t = q_sample(torus, t): the two forms cross at a walked share of ~0.6 -- 0.40: 8.11 vs 8.90 ms,
+    # 0.53: 8.57 vs 8.87, 0.68: 9.12 vs 8.86, 0.96: 9.92 vs 8.87; profiles/r5_bench.json `trajectory`)
+    WHOLE_ABOVE = 0.6
 
     def __init__(self, net, diffusion_hyperparams, noise='device', use_graph=True, neighbourhoods='adaptive'):
         """neighbourhoods: 'adaptive' (default; see the module docstring), 'once' / 'whole' = one form for every step
