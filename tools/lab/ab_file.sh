@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of two versions of one python file: r5_ab_file.sh <path in repo> <alternative file> [bench args]
+# same-box A/B of two versions of one python file: ab_file.sh <path in repo> <alternative file> [bench args]
 # prints ms/step of 3 alternating runs each (headline leg only)
 export TMPDIR=/tmp
 F=$1; ALT=$2; shift 2

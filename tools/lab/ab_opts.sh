@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of PDR_FUSED_OPTS settings: r5_ab_opts.sh "OPTS1" "OPTS2" ... ; "-" = defaults; 2 alternating rounds
+# same-box A/B of PDR_FUSED_OPTS settings: ab_opts.sh "OPTS1" "OPTS2" ... ; "-" = defaults; 2 alternating rounds
 export TMPDIR=/tmp
 run() { python bench.py --steps ${AB_STEPS:-60} --warmup 5 --no-cpu-baseline --no-roofline --no-extras ${AB_ARGS} 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.readline());print(d['ms_per_step'])"; }
 for r in 1 2; do
