@@ -48,3 +48,60 @@ def test_eight_rank_dry_run_gathers_in_rank_order():
     assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["world_size_after_gather"] == 8
     assert out["records_per_rank"] == [6] * 7 + [3] and out["records_gathered"] == 45
     assert out["rank_column_sorted"] and out["record_rank_runs"] == [[float(i), 6 if i < 7 else 3] for i in range(8)]
+
+
+_RCCL_ONE_RANK = r"""
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("PDR_TEST_PORT", "29731"), RANK="0",
+                  WORLD_SIZE="1", LOCAL_RANK="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", device_id=dev)          # bench.py main(), world > 1
+assert dist.get_backend() == "nccl"
+dist.barrier()
+t = torch.tensor([3.5], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                          # max-over-ranks timing
+rec = torch.arange(35, device=dev, dtype=torch.float32).view(7, 5)
+n = torch.tensor([7], dtype=torch.int64, device=dev)
+counts = [torch.zeros_like(n)]
+dist.all_gather(counts, n)                                        # generation.gather_records: lengths, then payload
+out = [torch.empty_like(rec)]
+dist.all_gather(out, rec)
+torch.cuda.synchronize()
+assert float(t) == 3.5 and int(counts[0]) == 7 and torch.equal(out[0], rec)
+dist.destroy_process_group()
+print("rccl-one-rank-ok")
+"""
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_rccl_backend_runs_the_jobs_collectives_on_this_box():
+    """What a 1-GPU box can say about the N-GPU job: the process group bench.py creates for world > 1 (backend
+    "nccl" = RCCL, device-bound) comes up on this box's GPU, and the collectives of the path -- barrier, the MAX
+    all-reduce of the timing, the two all-gathers of generation.gather_records -- run on device tensors.  (One rank:
+    gather_records itself returns early at world size 1, so the calls are made directly.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "rccl-one-rank-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_driver_launch_line_with_one_rank_on_the_gpu():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 ... bench.py --gpus 1` (the driver's line) on the
+    real device: environment parsing, the timed region and the JSON contract of the line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+                        "--no-extras"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["ranks_seen"] == 1 and out["world_size_after_gather"] == 1

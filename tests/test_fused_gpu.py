@@ -618,6 +618,21 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
         seg = (U.to(cuda), 0, Cin, ld, 1, {"V": (V2c, 0), "V0": (V2c, ld), "ldv": 2 * ld, "nsrc": n_src,
                                             "zrow": B * n_src})
         gidx = (idx.to(cuda), cnt.to(cuda))
+    elif kind == "knn":          # kNN-form gathered source: U[idx] + V + s1 r1 + s2 r2, no empty balls
+        n_src = 3 * K
+        U = torch.randn(B * n_src + 1, ld, generator=g)
+        V2 = torch.randn(P // K, ld, generator=g)
+        idx = torch.randint(0, n_src, (P,), generator=g, dtype=torch.int32)
+        s1, s2 = torch.rand(P, generator=g), torch.rand(P, generator=g)
+        r1, r2 = torch.randn(ld + 4, generator=g), torch.randn(ld + 4, generator=g)
+        q = torch.arange(P) // K
+        rows = U[bidx * n_src + idx.long()][:, :Cin] + V2[q][:, :Cin]
+        rows = rows + s1[:, None] * r1[None, :Cin] + s2[:, None] * r2[None, :Cin]
+        x = rows.double()
+        main_knn = (s1.to(cuda), s2.to(cuda), r1.to(cuda), r2.to(cuda))
+        seg = (U.to(cuda), 0, Cin, ld, 1, {"V": (V2.to(cuda), 0), "V0": None, "ldv": ld, "nsrc": n_src,
+                                            "zrow": B * n_src, "r1": (main_knn[2], 0), "r2": (main_knn[3], 0)})
+        gidx = (idx.to(cuda), None)
     else:
         t = torch.randn(P, ld, generator=g)
         x = t[:, :Cin].double()
@@ -680,6 +695,8 @@ def _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=32):
                  add_ld=Cin, radd=radd, pre_relu=pre, post_relu=post)
     if gidx is not None:
         act.gidx, act.gcnt, act.gK = gidx[0], gidx[1], K
+    if kind == "knn":
+        act.gs1, act.gs2 = main_knn[0], main_knn[1]
     if knn is not None:
         act.gs1, act.gs2 = knn[0], knn[1]
         # what SplitFirstConv hands consumers without a kNN-gathering kernel (run_layer's fallback)
@@ -738,6 +755,34 @@ def test_gathered_residual_on_wide_tiles(cuda, B, rpb, Cin, Cout, kind):
         assert _rel(got, ref) < 5e-5, (B, rpb, Cin, Cout, seed, _rel(got, ref))
         st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
         assert _rel(st[..., 0], ref.view(B, rpb, Cout).sum(1)) < 2e-4
+
+
+# (B = 8 / 16: the XCD-local tile order; 10: the plain one; 16384 rows per cloud at B = 8: eight tiles per persistent
+# workgroup, the launch shape of the dominant kernel of the step)
+@pytest.mark.parametrize("B,rpb,Cin,Cout,K", [(2, 256, 128, 128, 8), (8, 16384, 128, 128, 8), (10, 128 * 33, 96, 128, 8),
+                                              (16, 128 * 9, 160, 256, 16), (3, 192, 100, 96, 8), (2, 1024, 75, 64, 8)])
+def test_knn_gathered_source_on_wide_and_narrow_tiles(cuda, B, rpb, Cin, Cout, K):
+    """The kNN-form gathered first conv as the MAIN source (U[idx] + V + d2 r1 + w r2: the second convs of the
+    feature-propagation blocks, `fused_layer_ws_kernel<..., GATH = 2>` -- the dominant kernel of the step) against the
+    float64 layer, output and per-tile moments; whole and partial row tiles, channel counts that end inside a chunk."""
+    lib = _lib.load()
+    for seed in (5, 6, 15):
+        act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, "knn", K=K)
+        plan = (ctypes.c_int * 8)()
+        li = act.struct()
+        Y0 = torch.empty(1, device=cuda)
+        assert lib.pdr_fused_layer_plan(ctypes.byref(li), act.P, Cin, conv.Wt.data_ptr(), conv.ldw, Cout,
+                                        Y0.data_ptr(), (Cout + 3) // 4 * 4, plan) == 0
+        assert plan[0] == 1 and plan[3] == 2, list(plan[:6])      # wave-specialised, kNN-form gathered source
+        Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=Cout // 2)
+        torch.cuda.synchronize()
+        got = Y[:, :Cout].double().cpu()
+        assert torch.isfinite(got).all() and _rel(got, ref) < 5e-5, (B, rpb, Cin, Cout, seed, _rel(got, ref))
+        f = ref.clone()
+        f[:, Cout // 2:] = f[:, Cout // 2:].relu()
+        st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
+        assert _rel(st[..., 0], f.view(B, rpb, Cout).sum(1)) < 2e-4
+        assert _rel(st[..., 1], (f * f).view(B, rpb, Cout).sum(1)) < 2e-4
 
 
 @pytest.mark.timeout(300)

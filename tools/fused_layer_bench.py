@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--first", type=int, default=0, help="skip SHAPES before this index")
     ap.add_argument("--gath", type=int, default=0, help="K > 0: the source is a gathered first conv (U[idx] + V, K "
                                                          "neighbours per query, 2048 source points per cloud)")
+    ap.add_argument("--knn", action="store_true", help="with --gath: the kNN form (+ d2 r1 + w r2, no ball counts) -- "
+                                                        "the source of the feature-propagation blocks' second convs")
     ap.add_argument("--split", action="store_true", help="pdr_fused_layer_f16x3 (split-f16 arithmetic) where a tile "
                                                         "variant carries it")
     args = ap.parse_args()
@@ -70,6 +72,12 @@ def main():
             li.seg[0].gV, li.seg[0].gV0 = V2.data_ptr(), V2.data_ptr() + 4 * ldx
             li.seg[0].g_ldv, li.seg[0].g_nsrc, li.seg[0].g_zrow = 2 * ldx, n_src, B * n_src
             li.gidx, li.gcnt, li.gK = idx.data_ptr(), cnt.data_ptr(), K
+            if args.knn:
+                s1, s2 = torch.rand(P, device=dev), torch.rand(P, device=dev)
+                r1, r2 = torch.randn(ldx + 4, device=dev), torch.randn(ldx + 4, device=dev)
+                li.gcnt, li.seg[0].gV0 = None, None
+                li.gs1, li.gs2 = s1.data_ptr(), s2.data_ptr()
+                li.seg[0].g_r1, li.seg[0].g_r2 = r1.data_ptr(), r2.data_ptr()
         li.scale, li.shift = scale.data_ptr(), shift.data_ptr()
         li.pre_relu, li.post_relu, li.rows_per_batch = 0, 1, rpb
 
