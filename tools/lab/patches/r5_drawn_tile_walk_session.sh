@@ -1,6 +1,6 @@
 # Drawn tile walk (pdr_layer_in_t.tile_ctr) against the fixed stride, same box: tests, kernels alone on the chip,
 # per-workgroup run times (lab trace build, if present), the replayed step both ways.
-#   gpurun -- 'bash tools/lab/dyn_session.sh'   ->  gpurun_out/dyn_*.txt
+#   gpurun -- 'bash tools/lab/patches/r5_drawn_tile_walk_session.sh'   ->  gpurun_out/dyn_*.txt
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out
