@@ -936,7 +936,19 @@ struct LayerPlan {
   bool vec, gath, radd, ws, knn, thin;
   long ntiles;
   int ncol;
+  // right-sized launch of a tiny layer (see pdr_fused_layer): 0 = none, 5 / 4 = the 64 x 64 / 128 x 64 tiles of the
+  // uniform-wave kernel with 128-channel chunks in place of the wave-specialised 64 x 128 / 128 x 128 ones, 6 = 32-row
+  // tiles with 128-channel chunks
+  int deep;
 };
+
+bool deep_chunks() {
+  static const bool on = []() {
+    const char* e = getenv("PDR_DEEP_CHUNKS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 bool use_ws_kernels() {
   // tuning knob, read ONCE per process: PDR_FUSED_WS=0 selects the uniform-wave kernels (documented in pdr_hip.h)
@@ -1019,6 +1031,24 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   pl->radd = radd;
   // steady-state layers (float4-staged sources): wave-specialised kernel where an instantiation exists
   pl->ws = use_ws_kernels() && vec && pdr::fused_layer_ws_supported(t.id, radd, gath, *in, Cin);
+  // TINY layers (round 5; PDR_DEEP_CHUNKS=0: never).  The per-point layers of the deep levels are launches of a few
+  // dozen workgroups, each a serial walk over the input channels: their time is (chunks) x (load latency) + (MFMAs per
+  // wave) x 64 cycles on a chip that is half to seven eighths empty.  Where every workgroup of the launch is resident
+  // at once they run on the uniform-wave kernel with 128-channel chunks (a quarter of the round trips) and, for the
+  // 64- / 128-row tiles, half-width tiles (twice the workgroups, half the MFMAs per wave):
+  //   32-row tiles (batch elements of < 64 rows: 16 points per cloud), <= 256 jobs          -> 32 x 128, 128-channel chunks
+  //   64-row tiles (64 .. 127 rows: 64 points), plain sources, <= 512 jobs of 64 x 64       -> 64 x 64,  128-channel chunks
+  //   128-row tiles (128 .. 511 rows at B = 32: 256 points), plain sources, <= 128 jobs     -> 128 x 64, 128-channel chunks
+  // (128 for the last: beyond that every CU already holds a workgroup and the matrix pipes are what the launch waits
+  // for -- bound at 256 / 512: step 5.85 / 6.06 ms against 5.79 at 128, tools/lab/v4_jobs.sh.)  Measured alone on the
+  // chip, B = 32: 16 rows 512 -> 512 35.8 -> 27.6 us, 64 rows 256 -> 256 16.6 -> 14.0, 256 rows 128 -> 128 16.2 -> 12.5,
+  // 256 -> 256 26.7 -> 22.0, 512 rows 128 -> 128 17.2 -> 13.6; step 6.03 -> 5.87 ms (profiles/r5_tiny_layers_ab.txt).
+  pl->deep = 0;
+  if (deep_chunks() && Cin > 64 && !in->tile_list) {
+    if (t.id == 6 && pl->ntiles * pl->ncol <= 256) pl->deep = 6;
+    else if (t.id == 5 && vec && !gath && pl->ntiles * ((Cout + 63) / 64) <= 512) pl->deep = 5;
+    else if (t.id == 4 && vec && !gath && pl->ntiles * pl->ncol <= 128) pl->deep = 4;
+  }
   // <= 4 input channels, nothing to apply on the way in, 16-byte rows on both sides: the thin kernel (statistics
   // are decided by the caller: pdr_fused_layer uses it only without `partial`)
   pl->thin = vec && Cin <= 4 && in->n_seg == 1 && !gath && !radd && !in->scale && !in->shift && !in->add &&
@@ -1038,13 +1068,14 @@ extern "C" int pdr_fused_layer_plan(const pdr_layer_in_t* in, long P, int Cin, c
   LayerPlan pl;
   const int rc = plan_layer(in, P, Cin, Wt, ldw, Cout, Y, ldy, &pl);
   if (rc != PDR_OK) return rc;
-  out[0] = pl.ws;
+  out[0] = pl.ws && pl.deep != 4 && pl.deep != 5;
   out[1] = pl.t.id;
   out[2] = pl.radd;
   out[3] = pl.gath ? (pl.knn ? 2 : 1) : 0;
   out[4] = pl.vec;
   out[5] = 0;
   out[6] = pl.thin;
+  out[7] = pl.deep ? 128 : 0;   // channels per chunk of a right-sized tiny launch (plan_layer), else 0
   return PDR_OK;
 }
 
@@ -1083,6 +1114,22 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
                        __builtin_ctz(in->seg[0].row_div), Cin, Wt, ldw, bias, Cout, Y, ldy, P, qshift);
     return pdr::check_launch();
   }
+  if (pl.deep == 5 || pl.deep == 4) {   // right-sized tiny layer (plan_layer)
+    const dim3 g64(static_cast<unsigned>(ntiles), static_cast<unsigned>((Cout + 63) / 64));
+#define PDR_DEEP(RT, WR)                                                                                          \
+  do {                                                                                                            \
+    if (radd)                                                                                                     \
+      hipLaunchKernelGGL((fused_layer_kernel<RT, 1, WR, 2, 128, true, true, false>), g64, dim3(256), 0, s, *in, Cin, \
+                         Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);                                    \
+    else                                                                                                          \
+      hipLaunchKernelGGL((fused_layer_kernel<RT, 1, WR, 2, 128, false, true, false>), g64, dim3(256), 0, s, *in, Cin, \
+                         Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);                                    \
+  } while (0)
+    if (pl.deep == 5) PDR_DEEP(1, 2);
+    else PDR_DEEP(2, 2);
+#undef PDR_DEEP
+    return pdr::check_launch();
+  }
   if (pl.ws &&
       pdr::launch_fused_layer_ws(t.id, radd, gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt,
                                  ncol, s))
@@ -1113,7 +1160,10 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
     case 5: PDR_LAUNCH(1, 2, 2, 2, 32); break;
     case 7: PDR_LAUNCH(1, 1, 4, 1, 32); break;
     case 8: PDR_LAUNCH(1, 2, 4, 1, 32); break;
-    default: PDR_LAUNCH(1, 1, 1, 4, 32); break;
+    default:
+      if (pl.deep == 6) PDR_LAUNCH(1, 1, 1, 4, 128);   // right-sized tiny layer (plan_layer)
+      else PDR_LAUNCH(1, 1, 1, 4, 32);
+      break;
   }
 #undef PDR_LAUNCH
 #undef PDR_LAUNCH_V

@@ -577,14 +577,21 @@ def pack_f16x3(Wt, Cout, seg_widths, TN=128):
     return img.view(torch.int16).reshape(-1), len(chunks)
 
 
-def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial_ptr, relu_col0):
-    """Try the f16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel)."""
+def _run_layer_split(lib, act, conv, li, y_ptr, ldy, partial_ptr, relu_col0, tiny_exact=True):
+    """Try the f16x3 entry point; False when this layer is not carried by it (caller uses the exact kernel).
+    tiny_exact=False: also for the tiny layers that run_layer leaves to the exact kernel (kernel tests)."""
     if _PRECISION[0] != "split_f16" or conv.Cin < SPLIT_MIN_CIN:
         return False
     if torch.is_tensor(partial_ptr):                    # (callers may hand over the statistics tensor itself)
         partial_ptr = partial_ptr.data_ptr()
     variant = lib.pdr_fused_layer_variant(act.rpb, conv.Cout)
     if variant not in SPLIT_VARIANTS:
+        return False
+    # (a tiny layer -- a few dozen workgroups, bound by its serial chunk walk, not by the matrix pipes -- is faster on
+    # the exact right-sized launch than on the split tiles: pdr_fused_layer_plan out[7])
+    plan = (ctypes.c_int * 8)()
+    if lib.pdr_fused_layer_plan(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw, conv.Cout, y_ptr, ldy,
+                                plan) == _lib.PDR_OK and plan[7] and tiny_exact:
         return False
     TN = 64 if variant == 8 else 128
     key = tuple(sg[2] for sg in act.segs) + (TN,)

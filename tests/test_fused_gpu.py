@@ -297,6 +297,7 @@ _VARIANTS = [
     ("knn_thread", {"PDR_KNN_WAVE": "0"}, True), ("narrow_2wg", {"PDR_WS_NARROW3": "0"}, True),
     ("fold_1024_threads", {"PDR_GN_FOLD_SMALL": "0"}, False),
     ("xcd_plain", {"PDR_WS_XCD_ORDER": "0"}, True), ("xcd_all", {"PDR_WS_XCD_ORDER": "2"}, True),
+    ("tiny_layers_on_ordinary_tiles", {"PDR_DEEP_CHUNKS": "0"}, False),
     # evaluation variants of fused_network.py (module constants; PDR_FUSED_OPTS is the lab override)
     ("no_score_pool", {"PDR_FUSED_OPTS": "FUSE_SCORE_POOL=0"}, False),
     ("materialised_first", {"PDR_FUSED_OPTS": "USE_VIRTUAL_FIRST=0"}, False),
@@ -785,6 +786,38 @@ def test_knn_gathered_source_on_wide_and_narrow_tiles(cuda, B, rpb, Cin, Cout, K
         assert _rel(st[..., 1], (f * f).view(B, rpb, Cout).sum(1)) < 2e-4
 
 
+@pytest.mark.parametrize("B,rpb,Cin,Cout,deep", [
+    (32, 16, 512, 512, True), (4, 16, 320, 300, True), (32, 16, 643, 1163, False),      # 32-row tiles: <= 256 jobs
+    (32, 64, 256, 256, True), (8, 64, 200, 70, True), (32, 64, 515, 512, True), (32, 64, 323, 1097, False),
+    (32, 256, 128, 128, True), (2, 384, 331, 200, True), (32, 256, 387, 512, False), (32, 512, 128, 128, True),
+    (32, 256, 64, 128, False)])
+@pytest.mark.parametrize("kind", ["plain", "radd"])
+def test_right_sized_tiny_layers(cuda, B, rpb, Cin, Cout, deep, kind):
+    """The per-point layers of the deep levels (a few dozen workgroups per launch) run on the uniform-wave kernel with
+    128-channel chunks and half-width tiles where every workgroup of the launch is resident at once
+    (pdr_fused_layer_plan out[7]); the shapes of the DDPM step at B = 32, shapes on both sides of the job bounds, channel
+    counts that end inside a chunk, every prologue option, against the float64 layer (output and per-tile moments)."""
+    lib = _lib.load()
+    for seed in (4, 11, 26):
+        act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=16)
+        plan = (ctypes.c_int * 8)()
+        li = act.struct()
+        Y0 = torch.empty(1, device=cuda)
+        assert lib.pdr_fused_layer_plan(ctypes.byref(li), act.P, Cin, conv.Wt.data_ptr(), conv.ldw, Cout,
+                                        Y0.data_ptr(), (Cout + 3) // 4 * 4, plan) == 0
+        assert (plan[7] == 128) == deep and (not deep or plan[0] == 0 or plan[1] == 6), (list(plan), deep)
+        rc0 = (0, Cout // 2 + 1, Cout)[seed % 3]
+        Y, part, tpb = FN.run_layer(act, conv, stats=True, relu_col0=rc0)
+        torch.cuda.synchronize()
+        got = Y[:, :Cout].double().cpu()
+        assert torch.isfinite(got).all() and _rel(got, ref) < 5e-5, (kind, B, rpb, Cin, Cout, seed, _rel(got, ref))
+        f = ref.clone()
+        f[:, rc0:] = f[:, rc0:].relu()
+        st = part.view(B, tpb, Cout, 2).double().sum(1).cpu()
+        assert _rel(st[..., 0], f.view(B, rpb, Cout).sum(1)) < 2e-4, (kind, B, rpb, Cin, Cout, seed)
+        assert _rel(st[..., 1], (f * f).view(B, rpb, Cout).sum(1)) < 2e-4, (kind, B, rpb, Cin, Cout, seed)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("ws", ["1", "0"])
 def test_fused_layer_random_sweep(cuda, ws, monkeypatch):
@@ -925,7 +958,8 @@ def test_split_f16_layer_vs_float64(cuda, P, Cin, Cout, rpb, segs, monkeypatch):
     tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
     tpb = (rpb + tm - 1) // tm
     part = torch.empty((B * tpb, Cout, 2), device=cuda)
-    assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), "split path not taken"
+    assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout,
+                               tiny_exact=False), "split path not taken"
     err = ((Y[:, :Cout].double() - ref).abs() / bound)
     assert float(err.max()) < 2e-6, float(err.max())
     got = part.view(B, tpb, Cout, 2).double().sum(1)
@@ -960,7 +994,8 @@ def test_split_f16_representation_floor(cuda, magnitude, bar, monkeypatch):
     Y = torch.empty((P, FN._ldy(Cout)), device=cuda)
     tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
     part = torch.empty(((P // rpb) * ((rpb + tm - 1) // tm), Cout, 2), device=cuda)
-    assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), "split path not taken"
+    assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout,
+                               tiny_exact=False), "split path not taken"
     err = float(((Y[:, :Cout].double() - ref).abs() / bound).max())
     assert err < bar, err
 
@@ -988,8 +1023,8 @@ def test_split_f16_large_activations_saturate_instead_of_nan(cuda, monkeypatch):
         Y = torch.empty((P, FN._ldy(Cout)), device=cuda)
         tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
         part = torch.empty(((P // rpb) * ((rpb + tm - 1) // tm), Cout, 2), device=cuda)
-        assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout), \
-            "split path not taken"
+        assert FN._run_layer_split(lib, act, conv, act.struct(), Y.data_ptr(), Y.shape[1], part, Cout,
+                                   tiny_exact=False), "split path not taken"
         return Y[:, :Cout].double().cpu(), xin.double().cpu()
     Y, xd = run(inside)
     assert bool(torch.isfinite(Y).all())
@@ -1298,19 +1333,30 @@ def test_adaptive_sampler_picks_the_form_of_each_step_from_the_probe(cuda):
     """GraphedReverseSampler(neighbourhoods='adaptive') on the DDPM configuration: restarted on a finished surface
     (use_a_precomputed_XT, step = 6: full balls) it replays the step with every neighbourhood evaluated, from noise the
     deduplicated one; the published walked share matches the plans'; and whichever form a step takes, the samples equal
-    those of the two fixed forms to fp32 summation order (same CPU noise stream)."""
+    those of the two fixed forms to fp32 summation order (same CPU noise stream): after two steps to 2e-6 everywhere;
+    after six a 1e-8 difference may have met a near-tie of a sampling / ball decision in one form and not in the other
+    (it does with the round-5 tiny-layer kernels on this seed: tools/lab/forms_check.py -- 245 of 12288 coordinates
+    above 1e-4, max 6.5e-4, while the whole form against itself under PDR_DEEP_CHUNKS=0 stays at 1.4e-7), so the six-step
+    clouds are held to the bound a flipped cloud is held to everywhere in this suite."""
     net, fused, dh, x0, cond, label = _surface_sampler_inputs(cuda, 2)
-    outs, counts = {}, {}
-    for mode in ("adaptive", "once", "whole"):
-        s = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True, neighbourhoods=mode)
-        torch.manual_seed(7)
-        outs[mode] = s.sample((2, 2048, 3), cond, label, use_a_precomputed_XT=True, step=6, XT=x0)
-        counts[mode] = dict(s.mode_counts)
-        if mode == "adaptive":
-            assert s.walked_share is not None and s.walked_share > 0.8, s.walked_share
-    assert counts["adaptive"]["whole"] >= 4 and counts["once"]["whole"] == 0 and counts["whole"]["once"] == 0, counts
-    for mode in ("once", "whole"):
-        assert _rel(outs["adaptive"], outs[mode]) < 2e-4, mode
+    for steps in (2, 6):
+        outs, counts = {}, {}
+        for mode in ("adaptive", "once", "whole"):
+            s = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True, neighbourhoods=mode)
+            torch.manual_seed(7)
+            outs[mode] = s.sample((2, 2048, 3), cond, label, use_a_precomputed_XT=True, step=steps, XT=x0)
+            counts[mode] = dict(s.mode_counts)
+            if mode == "adaptive" and steps == 6:
+                assert s.walked_share is not None and s.walked_share > 0.8, s.walked_share
+        assert counts["once"]["whole"] == 0 and counts["whole"]["once"] == 0, counts
+        if steps == 6:
+            assert counts["adaptive"]["whole"] >= 4, counts
+        for mode in ("once", "whole"):
+            e = (outs["adaptive"] - outs[mode]).abs() / (outs[mode].abs() + 1.0)
+            if steps == 2:
+                assert float(e.max()) < 2e-6, (mode, float(e.max()))
+            else:
+                assert float(e.max()) < 1e-2 and float((e < 2e-4).float().mean()) > 0.95, (mode, float(e.max()))
     # from noise: the deduplicated form, chosen from the first step's probe
     s = GraphedReverseSampler(fused, util.calc_diffusion_hyperparams(5, 1e-4, 0.02), noise='cpu', use_graph=True)
     torch.manual_seed(7)

@@ -26,7 +26,11 @@ def instrument(records):
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            records.append((name, meta(a, k, out), e0, e1))
+            try:
+                m = meta(a, k, out)
+            except Exception:   # (a diagnostic: an entry point whose signature moved on keeps its time, loses its shape)
+                m = dict(P=0, Cin=0, Cout=0, bytes=0, flops=0)
+            records.append((name, m, e0, e1))
             return out
         return inner
 
@@ -44,7 +48,8 @@ def instrument(records):
         if act.radd is not None:
             vec = vec and len(act.segs) == 1 and aligned(act.radd)
         desc = "+".join("%d/%d%s" % (sg[2], sg[3], "" if aligned(sg) else "!") for sg in act.segs)
-        return dict(P=act.P, Cin=conv.Cin, Cout=conv.Cout, bytes=src_bytes + 4 * conv.Cout * act.P,
+        return dict(P=act.P, rpb=act.rpb, Cin=conv.Cin, Cout=conv.Cout, bytes=src_bytes + 4 * conv.Cout * act.P,
+                    listed=act.dd is not None, gath=act.gidx is not None,
                     flops=2 * act.P * conv.Cin * conv.Cout, vec=vec, desc=desc + (" radd" if act.radd is not None else ""))
 
     FN.run_layer = wrap("fused_layer", FN.run_layer, layer_meta)
@@ -67,6 +72,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--all", action="store_true", help="every layer launch in call order (with --single-stream: alone "
+                                                       "on the chip), grouped by shape at the end")
+    ap.add_argument("--single-stream", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -74,6 +82,8 @@ def main():
     records = []
     instrument(records)
     fused = FN.FusedCloudConditionNet(net)
+    if args.single_stream:
+        fused.two_streams = False
     x, cond, label = synthetic_batch(args.batch, seed=0, device=dev)
     ts = torch.full((args.batch,), 999.0, device=dev)
     with torch.no_grad():
@@ -101,6 +111,28 @@ def main():
         print("%-12s %9d %5d %5d %8.3f %8.0f %8.1f  %s %s" % (name, m["P"], m["Cin"], m["Cout"], ms,
                                                          m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9,
                                                          "" if m.get("vec", True) else "SCALAR", m.get("desc", "")))
+    if args.all:
+        from point_diffusion_refinement_amd import _lib
+        lib = _lib.load()
+        groups = defaultdict(lambda: [0, 0.0])
+        print("-- every layer launch in call order: P rpb Cin Cout variant us")
+        for ms, name, m in rows:
+            if name != "fused_layer":
+                continue
+            var = lib.pdr_fused_layer_variant(m["rpb"], m["Cout"])
+            tm = lib.pdr_fused_layer_tile_rows(m["rpb"], m["Cout"])
+            tiles = m["P"] // m["rpb"] * ((m["rpb"] + tm - 1) // tm)
+            key = (m["P"], m["rpb"], m["Cin"], m["Cout"], var, tiles, m["listed"], m["gath"])
+            groups[key][0] += 1
+            groups[key][1] += ms
+            print("%9d %6d %5d %5d v%d tiles %5d %s%s %8.1f" % (m["P"], m["rpb"], m["Cin"], m["Cout"], var, tiles,
+                                                               "L" if m["listed"] else "-", "G" if m["gath"] else "-",
+                                                               ms * 1e3))
+        print("-- by shape: P rpb Cin Cout variant row-tiles listed gathered: launches, total us, mean us")
+        for key, (n, ms) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+            print("%9d %6d %5d %5d v%d tiles %5d %s%s  x%2d %8.1f %7.1f" % (key[0], key[1], key[2], key[3], key[4], key[5],
+                                                                          "L" if key[6] else "-", "G" if key[7] else "-",
+                                                                          n, ms * 1e3, ms * 1e3 / n))
     nonvec = [(ms, m) for ms, name, m in rows if name == "fused_layer" and not m.get("vec", True)]
     print("non-vector fused_layer launches: %d, %.3f ms" % (len(nonvec), sum(r[0] for r in nonvec)))
 
