@@ -1040,7 +1040,7 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   //   64-row tiles (64 .. 127 rows: 64 points), plain sources, <= 512 jobs of 64 x 64       -> 64 x 64,  128-channel chunks
   //   128-row tiles (128 .. 511 rows at B = 32: 256 points), plain sources, <= 128 jobs     -> 128 x 64, 128-channel chunks
   // (128 for the last: beyond that every CU already holds a workgroup and the matrix pipes are what the launch waits
-  // for -- bound at 256 / 512: step 5.85 / 6.06 ms against 5.79 at 128, tools/lab/v4_jobs.sh.)  Measured alone on the
+  // for -- bound at 256 / 512: step 5.85 / 6.06 ms against 5.79 at 128.)  Measured alone on the
   // chip, B = 32: 16 rows 512 -> 512 35.8 -> 27.6 us, 64 rows 256 -> 256 16.6 -> 14.0, 256 rows 128 -> 128 16.2 -> 12.5,
   // 256 -> 256 26.7 -> 22.0, 512 rows 128 -> 128 17.2 -> 13.6; step 6.03 -> 5.87 ms (profiles/r5_tiny_layers_ab.txt).
   pl->deep = 0;
