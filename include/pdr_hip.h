@@ -23,7 +23,7 @@
  *   - return value: PDR_OK (0) or a negative PDR_E* code.  Nothing prints or
  *     calls exit() (contrast cuda_utils.h:30-39).  No hidden allocation, no
  *     device synchronisation, no mutable global state: calls are thread-safe and
- *     capturable into a hipGraph.  The only process-wide inputs are eight tuning
+ *     capturable into a hipGraph.  The only process-wide inputs are nine tuning
  *     knobs read ONCE from the environment (kernel selection only; results are
  *     identical, for the layer kernels and the GroupNorm fold up to fp32 / fp64
  *     summation order):
@@ -37,7 +37,8 @@
  *     PDR_WS_XCD_ORDER=0|2 (plain tile order for every layer kernel / XCD-local
  *     order for all of them; default 1 = XCD-local for the gathered ones),
  *     PDR_DEEP_CHUNKS=0 (the tiny per-point layers of the deep levels on the
- *     same tiles / 32-channel chunks as everything else, see pdr_fused_layer_plan).
+ *     same tiles / 32-channel chunks as everything else, see pdr_fused_layer_plan),
+ *     PDR_DEEP_KS=1 (those layers without the K split among a workgroup's waves).
  *     tests/test_fused_gpu.py::test_ddpm_forward_with_every_non_default_variant runs
  *     the full DDPM forward under each of them.
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
@@ -288,8 +289,9 @@ int pdr_fused_layer_variant(int rows_per_batch, int Cout);
  * split-f16 arithmetic?, thin kernel (<= 4 input channels, no prologue; used when `partial` is NULL)?}; out[7] = 128
  * when the launch is a RIGHT-SIZED TINY LAYER, else 0: a layer whose tiles number at most 256 (32-row tiles), 512 in
  * 64 x 64 tiles (64-row tiles, plain sources) or 128 (128-row tiles, plain sources) and has > 64 input channels runs on
- * the uniform-wave kernel with 128-channel chunks and 32 x 128 / 64 x 64 / 128 x 64 tiles (out[0] = 0 then) -- a launch
- * of a few dozen workgroups is bound by its serial chunk walk, not by the matrix pipes.  The rows of `partial` per
+ * the uniform-wave kernel with 128-channel chunks and 32 x 32 (the four waves of a workgroup each walk a quarter of
+ * the input channels) / 64 x 32 (two ways) / 128 x 64 tiles (out[0] = 0 then) -- a launch of a few dozen workgroups is
+ * bound by its serial chunk walk and its waves' MFMA chains, not by the matrix pipes.  The rows of `partial` per
  * batch element do not change (same row tiles).  PDR_DEEP_CHUNKS=0: never.
  * Same return codes as pdr_fused_layer.  Process-wide tuning knob read once: PDR_FUSED_WS=0 selects the uniform-wave kernels. */
 int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw, int Cout,

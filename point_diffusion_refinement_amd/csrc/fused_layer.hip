@@ -79,12 +79,16 @@ __device__ __forceinline__ float load_col(const ColSrc& s, long row) {
 // previous chunk, registers -> LDS after them: the loads overlap the matrix pipe.
 using pdr::PoolArgs;   // POOL epilogue (pdr_common.h)
 
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC, bool GATH, bool POOL = false>
+// KS (round 5): the four waves split the K walk KS ways -- wave (wr, wc, kq) multiplies the k-pairs kq, kq + KS, ... of
+// every chunk into its own accumulators, the partial products are summed through LDS before the epilogue (in the
+// fixed order kq = 0, 1, ...).  For the tiny layers of plan_layer: their time is the length of a wave's MFMA chain.
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, bool VEC, bool GATH, bool POOL = false, int KS = 1>
 __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
     const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
     float* __restrict__ partial, int relu_col0, int n_row_tiles, PoolArgs pool = PoolArgs()) {
-  static_assert(WR * WC == 4, "4 waves per workgroup");
+  static_assert(WR * WC * KS == 4, "4 waves per workgroup");
+  static_assert(KS == 1 || !POOL, "pooled epilogue: no K split");
   constexpr int TM = WR * RT * 32, TN = WC * CT * 32;
   // scalar A path: thread -> (column ac, rows ar0 + RSTEP i)
   constexpr int APT = TM * KC / 256;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
   __shared__ float red[WR][TN][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave % WR, wc = wave / WR;
+  const int wr = wave % WR, wc = KS == 1 ? wave / WR : (wave / WR) % WC, kq = KS == 1 ? 0 : wave / (WR * WC);
   const int il = lane & 31, hi = lane >> 5;
   const int rpb = in.rows_per_batch;
   const int tpb = (rpb + TM - 1) / TM;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
       }
       const bool more = sg < in.n_seg;
       if (more) fetch(sg, ks, cbase);  // in flight during the MFMAs below
-      for (int kk = 0; kk < ksteps; ++kk) {
+      for (int kk = (KS == 1 ? 0 : kq); kk < ksteps; kk += KS) {
         float a[RT], w[CT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) a[i] = As[2 * kk + hi][(wr * RT + i) * 32 + il];
@@ -355,6 +359,35 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
       if (!more) break;
     }
 
+    if constexpr (KS > 1) {
+      // sum the KS partial products of every MFMA tile: waves kq > 0 park their accumulators in the (now idle) W stage,
+      // waves kq = 0 add them in the order kq = 1, 2, ...; only those run the epilogue below
+      static_assert(sizeof(float) * (KS - 1) * WR * WC * RT * CT * 16 * 64 <= sizeof(Bs), "K-split scratch");
+      float* scr = &Bs[0][0];
+      __syncthreads();                 // every wave has read its last operands
+      if (kq > 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              scr[((((kq - 1) * WR * WC + wc * WR + wr) * RT * CT + i * CT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (kq == 0) {
+#pragma unroll
+        for (int q = 1; q < KS; ++q)
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                acc[i][j][r] += scr[((((q - 1) * WR * WC + wc * WR + wr) * RT * CT + i * CT + j) * 16 + r) * 64 + lane];
+      }
+    }
+    [[maybe_unused]] const bool epi_wave = kq == 0;      // uniform per wave
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8 (reg>>2) + 4 (lane>>5).
     // Full row tiles (the common case) store through ONE predicated region per 32-column tile:
     // per-element conditions would put every store in its own basic block, each opened by an
@@ -424,6 +457,9 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
     }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
+      if constexpr (KS > 1) {
+        if (!epi_wave) break;           // (K split: the other waves hold partial products only)
+      }
       const int cl = (wc * CT + j) * 32 + il_e;
       const int col = n0 + cl;
       const bool colok = col < Cout;
@@ -1039,6 +1075,8 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   //   32-row tiles (batch elements of < 64 rows: 16 points per cloud), <= 256 jobs          -> 32 x 128, 128-channel chunks
   //   64-row tiles (64 .. 127 rows: 64 points), plain sources, <= 512 jobs of 64 x 64       -> 64 x 64,  128-channel chunks
   //   128-row tiles (128 .. 511 rows at B = 32: 256 points), plain sources, <= 128 jobs     -> 128 x 64, 128-channel chunks
+  // and, for plain sources, the first two narrower still with the K walk split among the waves (pdr_fused_layer):
+  // 32 x 32 tiles / 4 ways, 64 x 32 tiles / 2 ways.
   // (128 for the last: beyond that every CU already holds a workgroup and the matrix pipes are what the launch waits
   // for -- bound at 256 / 512: step 5.85 / 6.06 ms against 5.79 at 128.)  Measured alone on the
   // chip, B = 32: 16 rows 512 -> 512 35.8 -> 27.6 us, 64 rows 256 -> 256 16.6 -> 14.0, 256 rows 128 -> 128 16.2 -> 12.5,
@@ -1112,6 +1150,30 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
                      static_cast<unsigned>((c4n + ql - 1) / ql));
     hipLaunchKernelGGL(fused_layer_thin_kernel, tgrid, dim3(256), 0, s, in->seg[0].ptr, in->seg[0].ld,
                        __builtin_ctz(in->seg[0].row_div), Cin, Wt, ldw, bias, Cout, Y, ldy, P, qshift);
+    return pdr::check_launch();
+  }
+  // ... and their waves split the K walk (fused_layer_kernel's KS): 4 ways on 32 x 32 tiles for the 32-row family (16
+  // rows per cloud: a wave's chain of Cin / 2 MFMAs was most of the launch), 2 ways on 64 x 32 tiles for the 64-row
+  // family; not for the 128-row family (128 x 32 tiles, measured: 256 rows 256 -> 256 22.0 -> 54.3 us -- four times the
+  // workgroups re-reading the same 128 input rows).  Plain sources.  PDR_DEEP_KS=1: no split (A/B).
+  static const bool deep_ks = []() {
+    const char* e = getenv("PDR_DEEP_KS");
+    return !(e && e[0] == '1');
+  }();
+  if ((pl.deep == 6 || pl.deep == 5) && deep_ks && vec && !gath) {
+#define PDR_DEEP_KS_LAUNCH(RT, WR, WC, KSV, TNV)                                                                    \
+  do {                                                                                                                \
+    const dim3 gk(static_cast<unsigned>(ntiles), static_cast<unsigned>((Cout + TNV - 1) / TNV));                      \
+    if (radd)                                                                                                         \
+      hipLaunchKernelGGL((fused_layer_kernel<RT, 1, WR, WC, 128, true, true, false, false, KSV>), gk, dim3(256), 0, s, \
+                         *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL((fused_layer_kernel<RT, 1, WR, WC, 128, false, true, false, false, KSV>), gk, dim3(256), 0, s, \
+                         *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, nt);                              \
+  } while (0)
+    if (pl.deep == 6) PDR_DEEP_KS_LAUNCH(1, 1, 1, 4, 32);
+    else PDR_DEEP_KS_LAUNCH(1, 2, 1, 2, 32);
+#undef PDR_DEEP_KS_LAUNCH
     return pdr::check_launch();
   }
   if (pl.deep == 5 || pl.deep == 4) {   // right-sized tiny layer (plan_layer)

@@ -298,6 +298,7 @@ _VARIANTS = [
     ("fold_1024_threads", {"PDR_GN_FOLD_SMALL": "0"}, False),
     ("xcd_plain", {"PDR_WS_XCD_ORDER": "0"}, True), ("xcd_all", {"PDR_WS_XCD_ORDER": "2"}, True),
     ("tiny_layers_on_ordinary_tiles", {"PDR_DEEP_CHUNKS": "0"}, False),
+    ("tiny_layers_without_k_split", {"PDR_DEEP_KS": "1"}, False),
     # evaluation variants of fused_network.py (module constants; PDR_FUSED_OPTS is the lab override)
     ("no_score_pool", {"PDR_FUSED_OPTS": "FUSE_SCORE_POOL=0"}, False),
     ("materialised_first", {"PDR_FUSED_OPTS": "USE_VIRTUAL_FIRST=0"}, False),
