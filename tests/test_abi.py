@@ -125,3 +125,39 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.pdr_fused_layer_f16x3(*args) == EINVAL                          # 8 tiles per batch element, stride 7
     plain = (C.byref(li), 2048, 64, 0x2000, 128, None, 128, 0x3000, 128, None, 128, None)
     assert lib.pdr_fused_layer(*plain) == EINVAL
+
+
+def test_plan_reports_right_sized_tiny_layers():
+    """pdr_fused_layer_plan is host logic (no launch): out[7] = 128 exactly for the tiny layers of DESIGN 4.9 -- more than
+    64 input channels and few enough row tiles that every workgroup of the launch is resident at once (32-row tiles:
+    <= 256 jobs of 32 x 128; 64-row tiles, plain sources: <= 512 jobs of 64 x 64; 128-row tiles, plain sources: <= 128
+    jobs) -- and out[0] (wave-specialised kernel) is 0 for the 64- / 128-row ones."""
+    import ctypes as C
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+
+    def plan(B, rpb, Cin, Cout, gathered=False):
+        li = _lib.LayerIn()
+        li.n_seg = 1
+        ld = (Cin + 3) // 4 * 4
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = 0x10000, Cin, ld, 1
+        li.rows_per_batch = rpb
+        if gathered:
+            li.seg[0].gV, li.seg[0].gV0, li.seg[0].g_ldv, li.seg[0].g_nsrc, li.seg[0].g_zrow = 0x20000, 0x20000 + 4 * ld, 2 * ld, 64, B * 64
+            li.gidx, li.gcnt, li.gK = 0x30000, 0x40000, 16
+        out = (C.c_int * 8)()
+        ldw = (Cout + 3) // 4 * 4
+        assert lib.pdr_fused_layer_plan(C.byref(li), B * rpb, Cin, 0x50000, ldw, Cout, 0x60000, ldw, out) == 0
+        return list(out)
+
+    for B, rpb, Cin, Cout, deep in [(32, 16, 512, 512, True), (32, 16, 643, 1163, False), (32, 16, 64, 512, False),
+                                    (32, 64, 256, 256, True), (32, 64, 323, 1097, False), (32, 256, 128, 128, True),
+                                    (32, 512, 128, 128, True), (32, 512, 256, 256, False), (32, 2048, 128, 128, False)]:
+        p = plan(B, rpb, Cin, Cout)
+        assert (p[7] == 128) == deep, (B, rpb, Cin, Cout, p)
+        if deep and rpb >= 64:
+            assert p[0] == 0, p                                   # not the wave-specialised kernel
+        if not deep and rpb >= 64:
+            assert p[0] == 1, p
+    assert plan(32, 64, 256, 256, gathered=True)[7] == 0           # gathered sources: the wave-specialised tiles
+    assert plan(32, 256, 128, 128, gathered=True)[7] == 0
