@@ -768,7 +768,7 @@ def test_knn_gathered_source_on_wide_and_narrow_tiles(cuda, B, rpb, Cin, Cout, K
     feature-propagation blocks, `fused_layer_ws_kernel<..., GATH = 2>` -- the dominant kernel of the step) against the
     float64 layer, output and per-tile moments; whole and partial row tiles, channel counts that end inside a chunk."""
     lib = _lib.load()
-    for seed in (5, 6, 15):
+    for seed in (5, 6):
         act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, "knn", K=K)
         plan = (ctypes.c_int * 8)()
         li = act.struct()
@@ -799,7 +799,7 @@ def test_right_sized_tiny_layers(cuda, B, rpb, Cin, Cout, deep, kind):
     (pdr_fused_layer_plan out[7]); the shapes of the DDPM step at B = 32, shapes on both sides of the job bounds, channel
     counts that end inside a chunk, every prologue option, against the float64 layer (output and per-tile moments)."""
     lib = _lib.load()
-    for seed in (4, 11, 26):
+    for seed in (4, 11):
         act, conv, ref = _narrow_case(seed, cuda, B, rpb, Cin, Cout, kind, K=16)
         plan = (ctypes.c_int * 8)()
         li = act.struct()
