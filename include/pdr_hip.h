@@ -22,23 +22,12 @@
  *     zero-initialised: every output element is written by the kernel.
  *   - return value: PDR_OK (0) or a negative PDR_E* code.  Nothing prints or
  *     calls exit() (contrast cuda_utils.h:30-39).  No hidden allocation, no
- *     device synchronisation, no mutable global state: calls are thread-safe and
- *     capturable into a hipGraph.  The only process-wide inputs are nine tuning
- *     knobs read ONCE from the environment (kernel selection only; results are
- *     identical, for the layer kernels and the GroupNorm fold up to fp32 / fp64
- *     summation order):
- *     PDR_FUSED_WS=0 (uniform-wave layer kernels), PDR_NARROW_KC32=0 (256-row
- *     tiles for outputs of <= 64 channels, see pdr_fused_layer_tile_rows),
- *     PDR_FPS_WAVE=0|2 (furthest-point-sampling kernel family, see
- *     pdr_furthest_point_sampling), PDR_KNN_WAVE=0 (thread-per-query instead of
- *     wave-per-query kNN for K <= 8), PDR_GN_FOLD_SMALL=0 (1024-thread
- *     GroupNorm fold workgroups), PDR_WS_NARROW3=0 (two instead of three
- *     co-resident workgroups per CU for the 128 x 32 tiles),
- *     PDR_WS_XCD_ORDER=0|2 (plain tile order for every layer kernel / XCD-local
- *     order for all of them; default 1 = XCD-local for the gathered ones),
- *     PDR_DEEP_CHUNKS=0 (the tiny per-point layers of the deep levels on the
- *     same tiles / 32-channel chunks as everything else, see pdr_fused_layer_plan),
- *     PDR_DEEP_KS=1 (those layers without the K split among a workgroup's waves).
+ *     device synchronisation: calls are thread-safe and capturable into a
+ *     hipGraph.  The library never reads the environment (ABI 0.2.0; rounds 1-5
+ *     read ten PDR_* variables once per process).  The only process-wide state is
+ *     the table of kernel-selection options of pdr_set_option below (which kernel
+ *     family / tile shape / tile order runs an op; results are identical, for the
+ *     layer kernels and the GroupNorm fold up to fp32 / fp64 summation order).
  *     tests/test_fused_gpu.py::test_ddpm_forward_with_every_non_default_variant runs
  *     the full DDPM forward under each of them.
  *   - validation covers pointers, sizes and alignment; VALUES are not inspected
@@ -63,10 +52,34 @@ extern "C" {
 
 typedef void *pdr_stream_t; /* hipStream_t */
 
-/* library version: major*10000 + minor*100 + patch */
+/* library version: major*10000 + minor*100 + patch.  A caller built against another minor version must not call the
+ * entry points listed for it below (the Python binding refuses to load a library of another version).
+ *   0.1.0 (100)  rounds 1-4.
+ *   0.2.0 (200)  round 5 grew three signatures without a bump: pdr_reverse_step gained probe_acc / probe_out
+ *                before `stream`, pdr_gn_fold gained nvalid_a / tpb_main_a / nvalid_b / tpb_main_b, pdr_layer_in_t gained
+ *                wrow0 / wmul / patch_values / patch_ld / patch_w before `reserved_`; round 6: probe_out is a 4-slot ring
+ *                (int[16]), pdr_set_option replaces the environment knobs, pdr_point_chain / pdr_point_chain_plan are
+ *                new. */
 int pdr_version(void);
 /* last hip error string seen by this thread after a PDR_ELAUNCH ("" if none) */
 const char *pdr_last_error(void);
+/* Kernel-selection options (process-wide, relaxed atomics; set them before capturing a hipGraph -- a captured launch
+ * keeps the kernel it was captured with).  Unknown name / value out of range: PDR_EINVAL.
+ *   name            default  values
+ *   fused_ws           1     0: uniform-wave layer kernels instead of the wave-specialised ones
+ *   narrow_kc32        1     0: 256-row tiles for outputs of <= 64 channels (see pdr_fused_layer_tile_rows)
+ *   fps_wave           1     rank-ordered one-wave FPS kernel: 0 never, 1 up to 256 points, 2 up to 4096
+ *   fps_lean           1     0: the round-1 resident FPS kernel instead of the instruction-lean one
+ *   knn_wave           1     0: thread-per-query instead of wave-per-query kNN for K <= 8
+ *   gn_fold_small      1     0: 1024-thread GroupNorm fold workgroups
+ *   ws_narrow3         1     0: two instead of three co-resident workgroups per CU for the 128 x 32 tiles
+ *   ws_xcd_order       1     tile order of the layer kernels: 0 plain, 1 XCD-local for the gathered ones, 2 for all
+ *   deep_chunks        1     0: the tiny per-point layers of the deep levels on the ordinary tiles (pdr_fused_layer_plan)
+ *   deep_ks            1     0: those layers without the K split among a workgroup's waves
+ * pdr_option_name(i): name of option i (0 <= i < number of options), NULL beyond -- lets a binding enumerate them. */
+int pdr_set_option(const char *name, int value);
+int pdr_get_option(const char *name, int *value);
+const char *pdr_option_name(int index);
 
 /* include/cuda_utils.h:13-19 opt_n_threads(): min(2^floor(log2 x), 512).  The FPS
  * tie order depends on this value; exported so callers and
@@ -484,8 +497,10 @@ int pdr_reverse_step(float *x, const float *eps, int ld_eps, const float *z, con
                      float *ts_out, unsigned long long *rng_state, int *ticket, long npoints, int mode,
                      int *probe_acc, int *probe_out, pdr_stream_t stream);
 /* (probe_acc / probe_out, both NULL or both set: the same last workgroup copies the two probe counters of this step
- * (pdr_dedup_prepare / pdr_dedup_probe) to probe_out -- device-visible pinned host memory: the sampler reads them a
- * step or two later to pick the captured step for the next x_t -- and zeroes probe_acc for the next step.) */
+ * (pdr_dedup_prepare / pdr_dedup_probe) into probe_out -- device-visible pinned host memory, int[16] = a ring of four
+ * slots {tiles walked, tiles, step counter t, 1}, slot t & 3 (ABI 101; ABI 100 wrote int[2]) -- and zeroes probe_acc for
+ * the next step.  The sampler reads the slot of ONE given step a step or two later to pick the captured step for the
+ * next x_t; the tag tells it when that slot has been overwritten, so its choices do not depend on timing.) */
 /* out (B, W; ld ldo) = row clamp(*t_dev, 0, T-1) of table (T, W; ld ldt), broadcast to B rows: one reverse step's
  * per-block step-embedding rows fc(t_emb) looked up in a table built once per schedule with pdr_embed_linear over all T
  * step values (the chain depends on t only; same bits as evaluating it per step).  W, ldt, ldo multiples of 4. */

@@ -22,7 +22,11 @@
  *     against the reference *Python* layers run over this oracle
  *     (tests/golden/make_golden.py);
  *   - kNN follows pytorch3d (un-vendored, unpinned dependency): PARITY
- *     UNPINNED at the equal-distance ordering.
+ *     UNPINNED at the equal-distance ordering.  pdr_oracle_knn is the contract
+ *     the kernels implement (ascending, lower index first); pdr_oracle_knn_mink
+ *     restates pytorch3d's published MinK and tests/test_oracle.py records
+ *     where the two differ (exactly equal distances only: which tied point is
+ *     kept at the K-th distance, and the order of ties inside the result).
  *
  * FP contraction model (build with -ffp-contract=off, all fusions explicit):
  * nvcc's default --fmad=true contracts a*a+b*b+c*c in the LLVM/NVVM order
@@ -314,6 +318,76 @@ int pdr_oracle_knn(const float *x, const float *y, int B, int n1, int n2, int K,
   }
   free(bd);
   free(bi);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- kNN, pytorch3d's published MinK
+ * The second restatement of the same third-party op (round 6): pytorch3d's brute-force kernels
+ * (pytorch3d/csrc/knn/knn.cu, every version V0-V3: one thread per query walks the points p2 = 0 .. P2-1 in index
+ * order, `dist += diff * diff` over the coordinates, `mink.add(dist, p2)`, then `mink.sort()`) keep the K best in the
+ * MinK / RegisterMinK structure of pytorch3d/csrc/utils/mink.cuh.  Its published algorithm, restated:
+ *   add(key, val): while fewer than K are held, append (slot = size) and move (max_key, max_idx) to the new slot when
+ *     key > max_key (strictly; the first slot starts it); afterwards a key replaces the slot max_idx only when
+ *     key < max_key (strictly), and the maximum is searched again: max_key = key, then every slot k = 0 .. K-1 with
+ *     keys[k] > max_key (strictly) takes it over -- among equal maxima the EARLIEST SLOT that beats the running value;
+ *   sort(): bubble sort of the slots, swapping neighbours only when keys[j + 1] < keys[j] (stable).
+ * The source is not under /root/reference (un-vendored, version unpinned by setup_env.sh:5): this is a restatement of
+ * the published code from memory of its structure, NOT a pin; tests/test_oracle.py compares it with pdr_oracle_knn (the
+ * contract the kernels implement: ascending, lower index first) and records where the two differ -- never in the
+ * distances, and in the indices only among EXACTLY equal distances: which of several points at the K-th distance is
+ * kept, and the order of equal distances inside the result (slot order = replacement history instead of index order).
+ * Same distance expression (ACC3) as pdr_oracle_knn.  K <= n2 rows are padded with dist 0 / idx -1 as there.
+ */
+int pdr_oracle_knn_mink(const float *x, const float *y, int B, int n1, int n2, int K,
+                        float *dists, int64_t *idx) {
+  float *keys = (float *)malloc(sizeof(float) * (size_t)K);
+  int64_t *vals = (int64_t *)malloc(sizeof(int64_t) * (size_t)K);
+  if (!keys || !vals) return -1;
+  for (int b = 0; b < B; ++b) {
+    const float *q = x + (size_t)b * n1 * 3;
+    const float *p = y + (size_t)b * n2 * 3;
+    for (int j = 0; j < n1; ++j) {
+      int size = 0, max_idx = 0;
+      float max_key = 0.0f;
+      const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+      for (int k = 0; k < n2; ++k) {
+        const float dx = qx - p[k * 3 + 0], dy = qy - p[k * 3 + 1],
+                    dz = qz - p[k * 3 + 2];
+        const float key = PDR_ACC3(dx, dy, dz);
+        if (size < K) {
+          keys[size] = key;
+          vals[size] = k;
+          if (size == 0 || key > max_key) {
+            max_key = key;
+            max_idx = size;
+          }
+          ++size;
+        } else if (key < max_key) {
+          keys[max_idx] = key;
+          vals[max_idx] = k;
+          max_key = key;
+          for (int t = 0; t < K; ++t) {
+            if (keys[t] > max_key) {
+              max_key = keys[t];
+              max_idx = t;
+            }
+          }
+        }
+      }
+      for (int i = 0; i < size - 1; ++i)
+        for (int t = 0; t < size - i - 1; ++t)
+          if (keys[t + 1] < keys[t]) {
+            const float kk = keys[t]; keys[t] = keys[t + 1]; keys[t + 1] = kk;
+            const int64_t vv = vals[t]; vals[t] = vals[t + 1]; vals[t + 1] = vv;
+          }
+      for (int t = 0; t < K; ++t) {
+        dists[((size_t)b * n1 + j) * K + t] = t < size ? keys[t] : 0.0f;
+        idx[((size_t)b * n1 + j) * K + t] = t < size ? vals[t] : -1;
+      }
+    }
+  }
+  free(keys);
+  free(vals);
   return 0;
 }
 

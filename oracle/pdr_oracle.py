@@ -150,6 +150,18 @@ def knn(x, y, K):
     return d, idx
 
 
+def knn_mink(x, y, K):
+    """The same op through the restatement of pytorch3d's published MinK (replace the current maximum on a strictly
+    smaller key, stable bubble sort): the comparison object of tests/test_oracle.py, not a contract of its own."""
+    x, y = _f32(x), _f32(y)
+    B, n1, _ = x.shape
+    n2 = y.shape[1]
+    d = np.zeros((B, n1, K), dtype=np.float32)
+    idx = np.zeros((B, n1, K), dtype=np.int64)
+    _chk(lib().pdr_oracle_knn_mink(_p(x), _p(y), B, n1, n2, int(K), _p(d), _p(idx)), "knn_mink")
+    return d, idx
+
+
 def knn_grad(x, y, idx, grad_dists):
     """Backward of knn(): (grad_x (B,n1,3), grad_y (B,n2,3))."""
     x, y, grad_dists = _f32(x), _f32(y), _f32(grad_dists)

@@ -20,6 +20,9 @@ _P, _I, _F, _Z = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 SIGNATURES = {
     "pdr_version": (_I, []),
     "pdr_last_error": (_c.c_char_p, []),
+    "pdr_set_option": (_I, [_c.c_char_p, _I]),
+    "pdr_get_option": (_I, [_c.c_char_p, _P]),
+    "pdr_option_name": (_c.c_char_p, [_I]),
     "pdr_opt_n_threads": (_I, [_I]),
     "pdr_fps_workspace_bytes": (_Z, [_I, _I]),
     "pdr_furthest_point_sampling": (_I, [_P, _I, _I, _I, _P, _P, _P]),
@@ -93,10 +96,11 @@ class LayerIn(_c.Structure):
                 ("wmul", _F), ("wrow0", _P), ("patch_values", _P), ("patch_w", _P), ("patch_ld", _I),
                 ("reserved_", _I)]
 _lib = None
+ABI_VERSION = 200          # pdr_version() this binding was written against (include/pdr_hip.h version history)
 
 
 def load():
-    """Load libpdr_hip.so; raise (never fall back) when it is missing."""
+    """Load libpdr_hip.so; raise (never fall back) when it is missing or of another ABI version."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -108,8 +112,46 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError = ABI mismatch, fail loudly
             fn.restype, fn.argtypes = res, args
+        if lib.pdr_version() != ABI_VERSION:
+            raise ImportError("point_diffusion_refinement_amd: %s is ABI %d, this binding needs %d -- rebuild it "
+                              "(`make -C %s/csrc`)" % (LIB_PATH, lib.pdr_version(), ABI_VERSION, _HERE))
         _lib = lib
+        _apply_env_options()
     return _lib
+
+
+def set_option(name, value):
+    """pdr_set_option: process-wide kernel-selection option (names / values: include/pdr_hip.h)."""
+    check(load().pdr_set_option(name.encode(), int(value)), "set_option(%s=%r)" % (name, value))
+
+
+def get_option(name):
+    v = _c.c_int(0)
+    check(load().pdr_get_option(name.encode(), _c.byref(v)), "get_option(%s)" % name)
+    return v.value
+
+
+def option_names():
+    lib, out, i = load(), [], 0
+    while True:
+        n = lib.pdr_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def _apply_env_options():
+    """The library itself never reads the environment (ABI 0.2.0).  For lab A/B runs and the variant tests, which
+    start a child process per setting, THIS binding maps PDR_OPTIONS="name=value,..." -- and the PDR_<NAME>=v variables
+    rounds 1-5 documented -- onto pdr_set_option once, at load."""
+    for item in filter(None, (t.strip() for t in os.environ.get("PDR_OPTIONS", "").split(","))):
+        name, _, val = item.partition("=")
+        set_option(name.strip(), int(val))
+    for name in option_names():
+        val = os.environ.get("PDR_" + name.upper())
+        if val is not None and val.strip().lstrip("-").isdigit():
+            set_option(name, int(val))
 
 
 def check(rc, what):

@@ -339,7 +339,7 @@ int launch_wave(const float* xyz, int B, int N, int m, int R, int Rbits, int Q, 
 //     instruction per step): the value (non-negative floats order like their bit patterns), then the key among the
 //     lanes that hold it: 12 + 6 instructions instead of 47.
 // Same picks as fps_resident_kernel for every input (tests/test_ops_gpu.py::test_fps_index_exact runs both:
-// PDR_FPS_LEAN=0 selects the old kernel).
+// option fps_lean = 0 selects the old kernel).
 __device__ __forceinline__ unsigned fps_wave_max_u32(unsigned v) {
   // lanes without a DPP source are disabled for that step and keep their own value; lane 63 ends with the maximum.
   // (two wait states between a VALU write of a register and a DPP read of it: the assembler does not insert them)
@@ -605,13 +605,9 @@ extern "C" int pdr_furthest_point_sampling(const float* xyz, int B, int N, int m
   //   4 waves, rank-ordered   532        127       20        665      (fewer VALU slots, but the round is a LATENCY
   //                                                                    chain: LDS read -> update -> tree -> 2 DPP
   //                                                                    reductions -> exchange -> index recovery)
-  // so it is used where it wins (<= 256 slots: no barrier at all).  PDR_FPS_WAVE (process-wide, read once):
+  // so it is used where it wins (<= 256 slots: no barrier at all).  Option fps_wave:
   // 0 = never, 2 = for every size up to 4096 slots (A/B and test runs).
-  static const int wave_mode = []() {
-    const char* e = getenv("PDR_FPS_WAVE");
-    // only "0", "1", "2" are meaningful; anything else keeps the default instead of silently disabling the path
-    return (e && (e[0] == '0' || e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 1;
-  }();
+  const int wave_mode = pdr::option(pdr::OPT_FPS_WAVE);
   const bool use_wave = wave_mode == 2 || (wave_mode == 1 && static_cast<long>(R) * Q <= 256);
   // the wave kernel keeps the cloud in N * 16 bytes of dynamic LDS next to its static exchange slots: stay inside
   // the 64 KiB a launch gets without raising hipFuncAttributeMaxDynamicSharedMemorySize, else the resident kernel
@@ -629,11 +625,8 @@ extern "C" int pdr_furthest_point_sampling(const float* xyz, int B, int N, int m
     return launch_wave<256, 16>(xyz, B, N, m, R, Rbits, Q, idx, s);
   }
   // instruction-lean resident kernel (fps_lean_kernel): clouds whose float4 image fits the 64 KiB a launch gets without
-  // raising the dynamic LDS limit, an even number of points per thread.  PDR_FPS_LEAN=0: the round-1 resident kernel.
-  static const bool lean = []() {
-    const char* e = getenv("PDR_FPS_LEAN");
-    return !(e && e[0] == '0');
-  }();
+  // raising the dynamic LDS limit, an even number of points per thread.  Option fps_lean = 0: the round-1 resident kernel.
+  const bool lean = pdr::option(pdr::OPT_FPS_LEAN) != 0;
   if (lean && N > 128 && static_cast<size_t>(N) * sizeof(float4) + 256 <= 64 * 1024) {
     if (N <= 512) return launch_lean<256, 2>(xyz, B, N, m, R, Rbits, Q, idx, s);
     if (N <= 1024) return launch_lean<256, 4>(xyz, B, N, m, R, Rbits, Q, idx, s);

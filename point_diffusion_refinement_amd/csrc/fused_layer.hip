@@ -929,14 +929,8 @@ namespace {
 struct TileCfg { int tm, tn, id; };
 // narrow outputs: 128-row tiles staged in 32-channel chunks (ids 7, 8) instead of 256-row tiles in 16-channel
 // chunks (ids 0, 1): a row of <= 32 channels is then fetched as ONE whole 128-byte line (the half-line fetches of
-// the 16-channel chunks were re-read from HBM).  PDR_NARROW_KC32=0: the 256-row tiles.
-inline bool narrow_kc32() {
-  static const bool on = []() {
-    const char* e = getenv("PDR_NARROW_KC32");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+// the 16-channel chunks were re-read from HBM).  Option narrow_kc32 = 0: the 256-row tiles.
+inline bool narrow_kc32() { return pdr::option(pdr::OPT_NARROW_KC32) != 0; }
 inline TileCfg pick_tile(int rows_per_batch, int Cout) {
   if (narrow_kc32() && rows_per_batch >= 128 && Cout <= 32) return {128, 32, 7};
   if (narrow_kc32() && rows_per_batch >= 128 && Cout <= 64) return {128, 64, 8};
@@ -978,22 +972,9 @@ struct LayerPlan {
   int deep;
 };
 
-bool deep_chunks() {
-  static const bool on = []() {
-    const char* e = getenv("PDR_DEEP_CHUNKS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+bool deep_chunks() { return pdr::option(pdr::OPT_DEEP_CHUNKS) != 0; }
 
-bool use_ws_kernels() {
-  // tuning knob, read ONCE per process: PDR_FUSED_WS=0 selects the uniform-wave kernels (documented in pdr_hip.h)
-  static const bool use_ws = []() {
-    const char* e = getenv("PDR_FUSED_WS");
-    return !(e && e[0] == '0');
-  }();
-  return use_ws;
-}
+bool use_ws_kernels() { return pdr::option(pdr::OPT_FUSED_WS) != 0; }
 
 int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int ldw, int Cout, const float* Y,
                int ldy, LayerPlan* pl) {
@@ -1067,7 +1048,7 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   pl->radd = radd;
   // steady-state layers (float4-staged sources): wave-specialised kernel where an instantiation exists
   pl->ws = use_ws_kernels() && vec && pdr::fused_layer_ws_supported(t.id, radd, gath, *in, Cin);
-  // TINY layers (round 5; PDR_DEEP_CHUNKS=0: never).  The per-point layers of the deep levels are launches of a few
+  // TINY layers (round 5; option deep_chunks = 0: never).  The per-point layers of the deep levels are launches of a few
   // dozen workgroups, each a serial walk over the input channels: their time is (chunks) x (load latency) + (MFMAs per
   // wave) x 64 cycles on a chip that is half to seven eighths empty.  Where every workgroup of the launch is resident
   // at once they run on the uniform-wave kernel with 128-channel chunks (a quarter of the round trips) and, for the
@@ -1155,11 +1136,8 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   // ... and their waves split the K walk (fused_layer_kernel's KS): 4 ways on 32 x 32 tiles for the 32-row family (16
   // rows per cloud: a wave's chain of Cin / 2 MFMAs was most of the launch), 2 ways on 64 x 32 tiles for the 64-row
   // family; not for the 128-row family (128 x 32 tiles, measured: 256 rows 256 -> 256 22.0 -> 54.3 us -- four times the
-  // workgroups re-reading the same 128 input rows).  Plain sources.  PDR_DEEP_KS=1: no split (A/B).
-  static const bool deep_ks = []() {
-    const char* e = getenv("PDR_DEEP_KS");
-    return !(e && e[0] == '1');
-  }();
+  // workgroups re-reading the same 128 input rows).  Plain sources.  Option deep_ks = 0: no split (A/B).
+  const bool deep_ks = pdr::option(pdr::OPT_DEEP_KS) != 0;
   if ((pl.deep == 6 || pl.deep == 5) && deep_ks && vec && !gath) {
 #define PDR_DEEP_KS_LAUNCH(RT, WR, WC, KSV, TNV)                                                                    \
   do {                                                                                                                \
@@ -1262,6 +1240,16 @@ extern "C" int pdr_fused_layer_f16x3(const pdr_layer_in_t* in, long P, int Cin, 
 // scores = prologue(X) . Wt + bias are consumed by the POOL epilogue:
 //   out[q, :] = sum_k softmax_k(mask(scores))[k, :] * act(values[q K + k, :] * vscale + vshift)
 // K in {8, 16, 32}; Cout = D (channels of scores, values and out).
+namespace {
+// pooled launch that also writes the pooled rows of the skipped tiles' queries (pdr_layer_in_t.patch_values): the
+// kernel reads patch_values / writes `out` in 16-byte pieces of 4 channels and reads patch_w[q] for every query
+bool pool_patch_args_ok(const pdr_layer_in_t& in, int D, const float* out, int ldo) {
+  if (!in.patch_values) return true;
+  return in.patch_w != nullptr && in.patch_ld >= D && D % 4 == 0 && in.patch_ld % 4 == 0 && ldo % 4 == 0 &&
+         reinterpret_cast<uintptr_t>(in.patch_values) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+}
+}  // namespace
+
 // pdr_fused_layer_pool with the score conv on split-f16 arithmetic (packed weight image as pdr_fused_layer_f16x3);
 // the 128-column wave-specialised tiles only: PDR_EUNSUPPORTED otherwise (the caller uses the exact entry point).
 extern "C" int pdr_fused_layer_pool_f16x3(const pdr_layer_in_t* in, long P, int Cin, const void* Wp, int nchunks,
@@ -1271,6 +1259,7 @@ extern "C" int pdr_fused_layer_pool_f16x3(const pdr_layer_in_t* in, long P, int 
   if (!in || !Wp || nchunks <= 0 || reinterpret_cast<uintptr_t>(Wp) % 16 != 0 || !values || !out || P <= 0 ||
       Cin <= 0 || D <= 0 || in->n_seg < 1 || in->n_seg > 4 || ldv < D || ldo < D)
     return PDR_EINVAL;
+  if (!pool_patch_args_ok(*in, D, out, ldo)) return PDR_EINVAL;
   if (!(K == 8 || K == 16 || K == 32)) return PDR_EUNSUPPORTED;
   if (in->rseg.ptr || in->oadd) return PDR_EUNSUPPORTED;
   int ctot = 0, nch = 0;
@@ -1308,6 +1297,7 @@ extern "C" int pdr_fused_layer_pool(const pdr_layer_in_t* in, long P, int Cin, c
   if (!in || !Wt || !values || !out || P <= 0 || Cin <= 0 || D <= 0 || in->n_seg < 1 || in->n_seg > 4 ||
       ldw < D || ldw % 4 != 0 || reinterpret_cast<uintptr_t>(Wt) % 16 != 0 || ldv < D || ldo < D)
     return PDR_EINVAL;
+  if (!pool_patch_args_ok(*in, D, out, ldo)) return PDR_EINVAL;
   if (!(K == 8 || K == 16 || K == 32)) return PDR_EUNSUPPORTED;
   if (in->rseg.ptr || in->oadd) return PDR_EUNSUPPORTED;
   int ctot = 0;
@@ -1387,10 +1377,7 @@ extern "C" int pdr_gn_fold(const float* part0, int ldp0, int tpb0, int C0, doubl
   // (without a subset: nv = tpb_main = 0 -- the range [nv, tpb_main) of skipped rows is empty)
   FoldPart p0{part0, ldp0, tpb0, C0, mult0, nvalid0, nvalid0 ? tpb_main0 : 0};
   FoldPart p1{part1, ldp1, tpb1, part1 ? C1 : 0, mult1, nvalid1, nvalid1 ? tpb_main1 : 0};
-  static const bool small_form = [] {
-    const char* e = getenv("PDR_GN_FOLD_SMALL");
-    return !(e && e[0] == '0');
-  }();
+  const bool small_form = pdr::option(pdr::OPT_GN_FOLD_SMALL) != 0;
   const int cpg = Cn > 0 ? Cn / G : 1;
   if (small_form && cpg <= 32) {
     // windows of whole groups covering <= 32 channels; one more workgroup row for pass-through channels

@@ -1060,15 +1060,12 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   // persistent: at most 2 workgroups per CU, all co-resident
   long gx = n_row_tiles;
   // persistent: every workgroup co-resident -- 2 per CU, 3 for the narrow tiles without a residual (see above);
-  // PDR_WS_NARROW3=0: 2 for all (A/B)
-  static const bool narrow3 = [] {
-    const char* e = getenv("PDR_WS_NARROW3");
-    return !(e && e[0] == '0');
-  }();
+  // option ws_narrow3 = 0: 2 for all (A/B)
+  const bool narrow3 = pdr::option(pdr::OPT_WS_NARROW3) != 0;
   // (launching only half of the co-resident workgroups, so that the kernels of the two block-half streams share every
   // CU instead of taking turns, measured 9.51 / 9.58 vs 8.78 / 8.79 ms per step in round 3 -- removed)
   const long resident = (narrow3 && id == 7 && !radd && !split) ? 768 : 512;
-  // PDR_WS_XCD_ORDER: 1 (default) = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer,
+  // Option ws_xcd_order: 1 (default) = XCD-local cloud-major tile order for the gathered kernels, 2 = for every layer,
   // 0 = plain.  Measured (same box, B = 32): HBM traffic of the kNN-gathered wide tiles 213.7 -> 170.5 MB per launch
   // (143 MB algorithmic), of the kNN-gathered narrow tiles 178 -> 143 MB, ball-gathered kernels unchanged; step time
   // 8.75 / 8.75 / 8.76 (plain) vs 8.79 / 8.69 / 8.78 (gathered kernels) vs 8.80 / 8.80 / 8.79 (all), and again at the
@@ -1076,10 +1073,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   // dominant kernel alone on the chip 149.3 / 149.3 us (plain) vs 152.3 / 149.8 us: a fifth fewer bytes at the same
   // time (the kernels are MFMA-bound), which is why the gathered kernels take it by default and the others do not.
   // Results are bit-identical (tools/lab/order_check.py, tests).
-  static const int xcd_knob = [] {
-    const char* e = getenv("PDR_WS_XCD_ORDER");
-    return e ? atoi(e) : 1;
-  }();
+  const int xcd_knob = pdr::option(pdr::OPT_WS_XCD_ORDER);
   const int tile_order = (xcd_knob >= 2 || (xcd_knob == 1 && gath)) ? 1 : 0;
   long cap = (resident + ncol - 1) / ncol;
   // (whole groups of 8 workgroups for the XCD-local walk; fewer than 8 resident column-block workgroups -- ncol > 64

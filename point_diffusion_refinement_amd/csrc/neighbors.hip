@@ -287,10 +287,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
 template <typename IdxT>
 bool launch_knn_wave(const float* x, const float* y, int B, int n1, int n2, int K, float* dists, IdxT* idx, float* nn,
                      float* wgt, hipStream_t s) {
-  static const bool on = [] {
-    const char* e = getenv("PDR_KNN_WAVE");
-    return !(e && e[0] == '0');
-  }();
+  const bool on = pdr::option(pdr::OPT_KNN_WAVE) != 0;
   if (!on || K > 8 || n2 < 64 || n2 > 1024) return false;
   // queries per wave: amortise the register fill of the cloud while the launch keeps >= 1024 workgroups (measured at
   // 2048 x 1024, B = 32: 4 / 8 / 16 queries per wave 60.6 / 60.1 / 60.3 us, 32: 88.6 us)

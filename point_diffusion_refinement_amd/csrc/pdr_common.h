@@ -29,6 +29,15 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Process-wide kernel-selection options (pdr_set_option / pdr_get_option of include/pdr_hip.h; the table with names,
+// defaults and ranges is in abi.hip).  Rounds 1-5 read ten of them from the environment inside the library; since ABI
+// 0.2.0 the library never looks at the environment -- the caller sets them.
+enum Opt {
+  OPT_FUSED_WS, OPT_NARROW_KC32, OPT_FPS_WAVE, OPT_FPS_LEAN, OPT_KNN_WAVE, OPT_GN_FOLD_SMALL, OPT_WS_NARROW3,
+  OPT_WS_XCD_ORDER, OPT_DEEP_CHUNKS, OPT_DEEP_KS, OPT_COUNT
+};
+int option(Opt o);
+
 // POOL epilogue of the layer kernels: the GEMM output is the attention SCORE of every (query, neighbour) position;
 // instead of being stored it is masked by the ball count, soft-maxed over the K neighbours of its query and used to
 // weight the value rows (attention.py:83-96) -- the (P x D) score tensor never exists.

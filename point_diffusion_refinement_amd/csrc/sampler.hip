@@ -138,10 +138,15 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(float* __restrict__ x
       if (ts_out && tn >= 0) *ts_out = ts_table ? ts_table[tn] : static_cast<float>(tn);
       if (rng) rng[1] += 1ull;
       if (probe_acc) {
-        // this step's neighbourhood probe (accumulated by the geometry launches long before this kernel) -> the slot
-        // the host polls; reset for the next step
-        probe_out[0] = probe_acc[0];
-        probe_out[1] = probe_acc[1];
+        // this step's neighbourhood probe (accumulated by the geometry launches long before this kernel) -> slot
+        // (t & 3) of the 4-slot ring the host reads, tagged with the step counter: the host asks for the probe of ONE
+        // given step and can tell a slot that a later step has already overwritten (a run's switch decisions then do
+        // not depend on how far the device has run ahead of the host); reset for the next step
+        int* slot = probe_out + 4 * static_cast<int>(tt & 3);
+        slot[0] = probe_acc[0];
+        slot[1] = probe_acc[1];
+        slot[2] = static_cast<int>(tt);
+        slot[3] = 1;                                   // written (a zeroed ring holds no valid slot)
         probe_acc[0] = 0;
         probe_acc[1] = 0;
       }

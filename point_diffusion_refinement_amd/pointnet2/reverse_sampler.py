@@ -26,8 +26,11 @@ balls are full, that chain is pure overhead.  The sampler therefore captures the
 each on first need) and picks per step on the host: every step counts, on the device, the tiles a deduplicated step
 walks / would walk (pdr_dedup_prepare / pdr_dedup_probe), the step's last kernel publishes the two counters into
 pinned host memory, and before launching step i the host waits for step i-2 (an event: the queue never runs dry, the
-GPU never waits) and reads them -- `once` while the walked share stays below WHOLE_ABOVE, `whole` above it.  Same
-results either way (the two forms differ by fp32 summation order of GroupNorm moments only).
+GPU never waits) and reads the slot THAT step published (a four-slot ring tagged with the step counter) -- `once` while
+the walked share stays below WHOLE_ABOVE, `whole` above it.  The choice is a function of the data, not of timing: a run
+repeated from the same seed replays the same forms.  Same results either way up to fp32 summation order of GroupNorm
+moments (1e-6 per step; over many steps a near-tie of an FPS pick can resolve differently between the forms, so
+`neighbourhoods='once'` / `'whole'` are the settings under which two DIFFERENT switch thresholds would still agree).
 """
 import torch
 
@@ -145,7 +148,10 @@ class GraphedReverseSampler:
             self.net.dedup = self._mode == 'once'
             # the probe counters travel only with the native step (its last kernel publishes and resets them)
             self.net.probe = self._probe if (native and self.neighbourhoods == 'adaptive') else None
-            self.net.step_table = (self._table(), self._t) if native else None
+            # (None when the network cannot build the table -- NATIVE_EMBED off, a t_dim / bank width outside the
+            # kernels' contract: the network then runs its per-step chain; ADVICE r5: a (None, t) pair crashed it)
+            tab = self._table() if native else None
+            self.net.step_table = (tab, self._t) if tab is not None else None
         try:
             eps = self.net(self._x, self._cond, ts=ts, label=self._label, use_retained_condition_feature=True)
             if native:
@@ -186,8 +192,9 @@ class GraphedReverseSampler:
             # neighbourhood probe: device counters (the network's geometry launches add to them, the step's last kernel
             # publishes and zeroes them) and their pinned, device-visible host copy
             self._probe = torch.zeros((2,), dtype=torch.int32, device=self.device)
-            self._probe_host = torch.zeros((2,), dtype=torch.int32).pin_memory() if self.device.type == "cuda" \
-                else torch.zeros((2,), dtype=torch.int32)
+            # (a ring of four slots {walked, tiles, step counter, written}: slot t & 3, pdr_reverse_step)
+            self._probe_host = torch.zeros((16,), dtype=torch.int32).pin_memory() if self.device.type == "cuda" \
+                else torch.zeros((16,), dtype=torch.int32)
             self._events = []
         self._cond.copy_(condition)
         if label is not None:
@@ -272,13 +279,17 @@ class GraphedReverseSampler:
         self.remaining = t0 + 1
         self._mode = 'whole' if self.neighbourhoods == 'whole' else 'once'
         self._probe.zero_()
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()   # (nothing of the previous batch still publishes)
+        self._probe_host.zero_()                       # no slot of the previous batch can be mistaken for this one's
         self._events = []
         self._advance_eager(keep_slice)                # first step: condition branch runs and is retained
         if self.neighbourhoods == 'adaptive' and self.device.type == "cuda":
             # once per batch: the first step's probe decides the form of the second (a restart from a stored x^step
-            # begins on a surface); later steps read the probe of two steps before without waiting for the device
+            # begins on a surface); later steps read the probe of the step two before them, by its step counter (a
+            # first step that ran in PyTorch ops -- keep_slice -- published nothing: the default form stays)
             torch.cuda.current_stream(self.device).synchronize()
-            self._pick_mode()
+            self._pick_mode(t0)
         if self._graphs:
             self._adopt_cache()
         if hasattr(self.net, "sync_condition"):
@@ -296,12 +307,19 @@ class GraphedReverseSampler:
         self._step(keep_slice)
         self.remaining -= 1
 
-    def _pick_mode(self):
-        """Form of the next step from the newest published probe (host memory; no device wait)."""
-        walked, total = int(self._probe_host[0]), int(self._probe_host[1])
-        if total > 0:
+    def _pick_mode(self, t):
+        """Form of the next step from the probe the step with counter `t` published (pinned host memory, slot t & 3 of
+        the ring, tagged with t: the caller has waited for that step, and a later step that has already overwritten the
+        slot -- it cannot, with two steps in flight and four slots -- or a step that published nothing leaves the form
+        as it is).  The choice therefore depends on the data only, not on how far the device has run ahead: two runs
+        from one seed replay the same forms."""
+        slot = self._probe_host[4 * (t & 3):4 * (t & 3) + 4].tolist()
+        walked, total, tag, written = slot
+        if written and tag == t and total > 0:
             self._mode = 'whole' if walked > self.WHOLE_ABOVE * total else 'once'
-        self.walked_share = walked / total if total > 0 else None
+            self.walked_share = walked / total
+        elif not (written and tag == t):
+            self.walked_share = None
 
     @torch.no_grad()
     def advance(self, n=1):
@@ -312,8 +330,9 @@ class GraphedReverseSampler:
             if adaptive and self.device.type == "cuda":
                 # wait for the step before the previous one (keeps two steps queued), then read what it published
                 if len(self._events) >= 2:
-                    self._events.pop(0).synchronize()
-                    self._pick_mode()
+                    ev, t_ev = self._events.pop(0)
+                    ev.synchronize()
+                    self._pick_mode(t_ev)
             if not self.use_graph:
                 self._advance_eager()
             else:
@@ -326,7 +345,7 @@ class GraphedReverseSampler:
             if adaptive and self.device.type == "cuda":
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
-                self._events.append(ev)
+                self._events.append((ev, self.remaining))       # (the step just queued ran with counter `remaining`)
 
     @torch.no_grad()
     def finish(self):

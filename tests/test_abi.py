@@ -26,7 +26,7 @@ def test_python_binding_covers_header():
     from point_diffusion_refinement_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
     lib = _lib.load()
-    assert lib.pdr_version() == 100
+    assert lib.pdr_version() == 200
 
 
 def test_opt_n_threads_matches_reference_table():
@@ -125,6 +125,62 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.pdr_fused_layer_f16x3(*args) == EINVAL                          # 8 tiles per batch element, stride 7
     plain = (C.byref(li), 2048, 64, 0x2000, 128, None, 128, 0x3000, 128, None, 128, None)
     assert lib.pdr_fused_layer(*plain) == EINVAL
+
+
+def test_options_replace_the_environment_knobs():
+    """ABI 0.2.0: the library never reads the environment; its kernel-selection options are set and
+    read back through pdr_set_option / pdr_get_option, enumerated by pdr_option_name, validated by name and range."""
+    import subprocess
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+    names = _lib.option_names()
+    assert names == ["fused_ws", "narrow_kc32", "fps_wave", "fps_lean", "knn_wave", "gn_fold_small", "ws_narrow3",
+                     "ws_xcd_order", "deep_chunks", "deep_ks"]
+    assert lib.pdr_option_name(len(names)) is None and lib.pdr_option_name(-1) is None
+    assert all(_lib.get_option(n) == 1 for n in names)                          # the defaults
+    assert lib.pdr_set_option(b"fps_wave", 3) == _lib.PDR_EINVAL and lib.pdr_set_option(b"fps_wave", -1) == _lib.PDR_EINVAL
+    assert lib.pdr_set_option(b"no_such_option", 1) == _lib.PDR_EINVAL and lib.pdr_set_option(None, 1) == _lib.PDR_EINVAL
+    assert lib.pdr_get_option(b"fps_wave", None) == _lib.PDR_EINVAL
+    _lib.set_option("fps_wave", 2)
+    _lib.set_option("ws_xcd_order", 0)
+    try:
+        assert _lib.get_option("fps_wave") == 2 and _lib.get_option("ws_xcd_order") == 0
+        # tile geometry follows the option at once (no "read once per process"): narrow outputs
+        assert lib.pdr_fused_layer_tile_rows(65536, 32) == 128
+        _lib.set_option("narrow_kc32", 0)
+        assert lib.pdr_fused_layer_tile_rows(65536, 32) == 256
+    finally:
+        for n in names:
+            _lib.set_option(n, 1)
+    # no getenv in the shipped library
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out, "libpdr_hip.so imports getenv"
+
+
+def test_pooled_launch_validates_its_patch_arguments_without_a_gpu():
+    """pdr_layer_in_t.patch_values makes the pooled launch read 16-byte pieces of patch_values / patch_w and
+    write 16-byte pieces of `out`: a missing weight array, a stride below D, widths / strides that are not multiples of
+    four floats and unaligned pointers are argument errors, decided on the host by both pooled entry points."""
+    import ctypes as C
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+
+    def call(fn, D=64, ldo=64, out=0x7000, **patch):
+        li = _lib.LayerIn()
+        li.n_seg = 1
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = 0x1000, 64, 64, 1
+        li.rows_per_batch = 4096
+        li.patch_values, li.patch_w, li.patch_ld = patch.get("values", 0x8000), patch.get("w", 0x9000), patch.get("ld", 64)
+        if fn == "exact":
+            return lib.pdr_fused_layer_pool(C.byref(li), 0, 64, 0x2000, 64, None, D, 0x3000, 64, None, None, 1, None, 32,
+                                            out, ldo, None)
+        return lib.pdr_fused_layer_pool_f16x3(C.byref(li), 0, 64, 0x2000, 2, None, D, 0x3000, 64, None, None, 1, None, 32,
+                                              out, ldo, None)
+    for fn in ("exact", "split"):
+        assert call(fn, w=None) == _lib.PDR_EINVAL
+        assert call(fn, ld=60) == _lib.PDR_EINVAL and call(fn, ld=66) == _lib.PDR_EINVAL
+        assert call(fn, values=0x8004) == _lib.PDR_EINVAL and call(fn, out=0x7008) == _lib.PDR_EINVAL
+        assert call(fn, D=62, ldo=64) == _lib.PDR_EINVAL and call(fn, ldo=66) == _lib.PDR_EINVAL
 
 
 def test_plan_reports_right_sized_tiny_layers():

@@ -48,6 +48,10 @@ def test_eight_rank_dry_run_gathers_in_rank_order():
     assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["world_size_after_gather"] == 8
     assert out["records_per_rank"] == [6] * 7 + [3] and out["records_gathered"] == 45
     assert out["rank_column_sorted"] and out["record_rank_runs"] == [[float(i), 6 if i < 7 else 3] for i in range(8)]
+    # every rank's own time beside the MAX the value is computed from
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["max"] == max(pr["ms_per_step"]) and pr["min"] == min(pr["ms_per_step"])
+    assert pr["ms_per_step"][pr["rank_of_max"]] == pr["max"] and abs(out["ms_per_step"] - pr["max"]) < 1e-3
 
 
 _RCCL_ONE_RANK = r"""

@@ -272,7 +272,7 @@ def test_fused_network_ddpm_config_and_graphed_sampler(cuda):
 
 
 def test_xcd_local_tile_order_is_bit_identical(cuda, tmp_path):
-    """PDR_WS_XCD_ORDER (read once per process -> two subprocesses): the XCD-local cloud-major tile order of the layer
+    """Option ws_xcd_order (set through the child's binding -> two subprocesses): the XCD-local cloud-major tile order of the layer
     kernels changes WHICH workgroup computes a tile, never the tile: one uncached + three cached reverse steps of the
     DDPM config at B = 8 give identical bytes under the plain order and under the XCD-local order for every layer."""
     import os
@@ -282,7 +282,7 @@ def test_xcd_local_tile_order_is_bit_identical(cuda, tmp_path):
     outs = []
     for order in ("0", "2"):
         path = str(tmp_path / ("x%s.pt" % order))
-        env = dict(os.environ, PDR_WS_XCD_ORDER=order, ORDER_CHECK_B="8")
+        env = dict(os.environ, PDR_OPTIONS="ws_xcd_order=" + order, ORDER_CHECK_B="8")
         subprocess.check_call([sys.executable, "-m", "tools.lab.order_check", path], cwd=root, env=env,
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         outs.append(torch.load(path))
@@ -291,14 +291,16 @@ def test_xcd_local_tile_order_is_bit_identical(cuda, tmp_path):
 
 # (name, environment, must be bit-identical to the default run)
 _VARIANTS = [
-    # kernel-selection knobs of libpdr_hip.so (include/pdr_hip.h; read once per process)
-    ("ws_off", {"PDR_FUSED_WS": "0"}, False), ("narrow_kc16", {"PDR_NARROW_KC32": "0"}, False),
-    ("fps_wave0", {"PDR_FPS_WAVE": "0"}, True), ("fps_wave2", {"PDR_FPS_WAVE": "2"}, True),
-    ("knn_thread", {"PDR_KNN_WAVE": "0"}, True), ("narrow_2wg", {"PDR_WS_NARROW3": "0"}, True),
-    ("fold_1024_threads", {"PDR_GN_FOLD_SMALL": "0"}, False),
-    ("xcd_plain", {"PDR_WS_XCD_ORDER": "0"}, True), ("xcd_all", {"PDR_WS_XCD_ORDER": "2"}, True),
-    ("tiny_layers_on_ordinary_tiles", {"PDR_DEEP_CHUNKS": "0"}, False),
-    ("tiny_layers_without_k_split", {"PDR_DEEP_KS": "1"}, False),
+    # kernel-selection options of libpdr_hip.so (pdr_set_option, include/pdr_hip.h; the child's binding applies
+    # PDR_OPTIONS at load -- the library itself never reads the environment)
+    ("ws_off", {"PDR_OPTIONS": "fused_ws=0"}, False), ("narrow_kc16", {"PDR_OPTIONS": "narrow_kc32=0"}, False),
+    ("fps_wave0", {"PDR_OPTIONS": "fps_wave=0"}, True), ("fps_wave2", {"PDR_OPTIONS": "fps_wave=2"}, True),
+    ("fps_resident", {"PDR_OPTIONS": "fps_lean=0"}, True),
+    ("knn_thread", {"PDR_OPTIONS": "knn_wave=0"}, True), ("narrow_2wg", {"PDR_OPTIONS": "ws_narrow3=0"}, True),
+    ("fold_1024_threads", {"PDR_OPTIONS": "gn_fold_small=0"}, False),
+    ("xcd_plain", {"PDR_OPTIONS": "ws_xcd_order=0"}, True), ("xcd_all", {"PDR_OPTIONS": "ws_xcd_order=2"}, True),
+    ("tiny_layers_on_ordinary_tiles", {"PDR_OPTIONS": "deep_chunks=0"}, False),
+    ("tiny_layers_without_k_split", {"PDR_OPTIONS": "deep_ks=0"}, False),
     # evaluation variants of fused_network.py (module constants; PDR_FUSED_OPTS is the lab override)
     ("no_score_pool", {"PDR_FUSED_OPTS": "FUSE_SCORE_POOL=0"}, False),
     ("materialised_first", {"PDR_FUSED_OPTS": "USE_VIRTUAL_FIRST=0"}, False),
@@ -822,11 +824,11 @@ def test_right_sized_tiny_layers(cuda, B, rpb, Cin, Cout, deep, kind):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("ws", ["1", "0"])
 def test_fused_layer_random_sweep(cuda, ws, monkeypatch):
-    """60 random layer problems through both kernel families (PDR_FUSED_WS is read once per process, so the
+    """60 random layer problems through both kernel families (option fused_ws is applied by the child binding, so the
     uniform-wave family is exercised in a child process)."""
     if ws == "0":
         import subprocess, sys, os
-        env = dict(os.environ, PDR_FUSED_WS="0", PDR_SWEEP_CHILD="1")
+        env = dict(os.environ, PDR_OPTIONS="fused_ws=0", PDR_SWEEP_CHILD="1")
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                             "random_sweep and 1"], env=env, capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -415,7 +415,7 @@ def test_reverse_step_update_bookkeeping_and_noise(cuda, mode):
     st = torch.cuda.current_stream().cuda_stream
     ticket = torch.zeros(1, dtype=torch.int32, device=cuda)
     acc = torch.zeros(2, dtype=torch.int32, device=cuda)
-    published = torch.zeros(2, dtype=torch.int32).pin_memory()             # pinned host memory, written by the kernel
+    published = torch.zeros(16, dtype=torch.int32).pin_memory()            # pinned host memory: the 4-slot probe ring
     for step, table in ((T - 1, None), (7, tau), (0, None)):
         t = torch.tensor([step], dtype=torch.int64, device=cuda)
         ts = torch.full((1,), -5.0, device=cuda)
@@ -431,7 +431,8 @@ def test_reverse_step_update_bookkeeping_and_noise(cuda, mode):
         assert int(t) == step - 1 and int(ticket) == 0
         # the neighbourhood probe of the step: published to the (host-visible) slot and reset by the same last workgroup
         torch.cuda.synchronize()
-        assert published.tolist() == [17 + step, 40] and acc.tolist() == [0, 0]
+        slot = 4 * (step & 3)                                  # slot t & 3 = {walked, tiles, step counter, written}
+        assert published[slot:slot + 4].tolist() == [17 + step, 40, step, 1] and acc.tolist() == [0, 0]
         expect_ts = -5.0 if step == 0 else (float(tau[step - 1]) if table is not None else float(step - 1))
         assert float(ts) == expect_ts
     # in-kernel noise: isolate z through x = 0, eps = 0, coefficients (a, b, c) = (1, 1, 1)

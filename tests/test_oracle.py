@@ -193,6 +193,70 @@ def test_knn_equal_distances_lower_index_first():
     assert i[0, 0].tolist() == [0, 1, 2] and d[0, 0].tolist() == [1, 1, 1]
 
 
+def test_knn_contract_against_the_published_mink_algorithm():
+    """VERDICT r5 item 8 / missing 3: the kernels' contract (pdr_oracle_knn: ascending, equal distances by lower index)
+    next to a restatement of pytorch3d's published MinK (pdr_oracle_knn_mink: a strictly smaller key replaces the
+    current maximum, stable bubble sort).  pytorch3d is not vendored, so neither is a pin; what this test establishes
+    and records is the EXTENT of the divergence:
+      * tie-free clouds (the measure-one case: random float coordinates): identical indices and distances, K = 1 and 8;
+      * K = 1 (Chamfer), any input: identical -- both keep the first minimum;
+      * exact ties (lattice, duplicated points), K = 8: the DISTANCES are identical everywhere, the indices differ only
+        inside groups of exactly equal distance -- as a different ORDER of the same points, or, at the K-th distance,
+        as a different CHOICE among the tied points (MinK evicts the slot that happened to hold the maximum, the
+        contract evicts the highest index)."""
+    rr = rng(2026)
+    # tie-free
+    x = rr.uniform(-1, 1, (3, 257, 3)).astype(np.float32)
+    y = rr.uniform(-1, 1, (3, 300, 3)).astype(np.float32)
+    for K in (1, 3, 8):
+        d0, i0 = O.knn(x, y, K)
+        d1, i1 = O.knn_mink(x, y, K)
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1), K
+    # exact ties: an integer lattice with duplicated points, queries on lattice points and cell centres
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+    yl = np.concatenate([g, g[20:60], g[::4]]).astype(np.float32)[None]                  # 197 points
+    yl = yl[:, rr.permutation(yl.shape[1])]
+    xl = np.concatenate([g[::3].astype(np.float32), g[:40].astype(np.float32) + 0.5])[None]
+    d0, i0 = O.knn(xl, yl, 1)
+    d1, i1 = O.knn_mink(xl, yl, 1)
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)                              # K = 1: first minimum, both
+    d0, i0 = O.knn(xl, yl, 8)
+    d1, i1 = O.knn_mink(xl, yl, 8)
+    assert np.array_equal(d0, d1)                                                         # same distances, always
+    nq = xl.shape[1]
+    order_only = set_differs = same = 0
+    for q in range(nq):
+        a, b = i0[0, q], i1[0, q]
+        if np.array_equal(a, b):
+            same += 1
+            continue
+        # every position holds a point at that position's distance in both results
+        full = ((xl[0, q][None].astype(np.float64) - yl[0].astype(np.float64)) ** 2).sum(-1)
+        assert np.array_equal(full[a].astype(np.float32), d0[0, q]) and np.array_equal(full[b].astype(np.float32), d0[0, q])
+        if set(a.tolist()) == set(b.tolist()):
+            order_only += 1
+        else:
+            set_differs += 1
+            # the symmetric difference sits at the K-th distance (the only place a choice exists)
+            diff = set(a.tolist()) ^ set(b.tolist())
+            assert all(np.float32(full[j]) == d0[0, q, -1] for j in diff), (q, diff)
+    assert order_only + set_differs > 0, "the lattice was meant to produce ties"
+    # the contract's own rule on the same input: equal distances ascend in index
+    for q in range(nq):
+        for t in range(7):
+            if d0[0, q, t] == d0[0, q, t + 1]:
+                assert i0[0, q, t] < i0[0, q, t + 1]
+    import json
+    import os
+    rec = {"queries": nq, "K": 8, "identical": same, "same_set_other_order": order_only, "other_tied_point_kept": set_differs,
+           "distances_identical": True, "tie_free_identical": True, "k1_identical": True}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "knn_mink_divergence.json"), "w") as f:
+            json.dump(rec, f)
+    print("kNN contract vs published MinK on a lattice with duplicates:", rec)
+
+
 def test_three_nn_is_squared_and_cascaded():
     rr = rng(7)
     u = rr.uniform(-1, 1, (2, 90, 3)).astype(np.float32)

@@ -43,7 +43,8 @@ def _time_replays(sampler, mode, x, counter, ts_value, reps):
         e1.record()
         torch.cuda.synchronize(dev)
         times.append(e0.elapsed_time(e1))
-    walked, total = int(sampler._probe_host[0]), int(sampler._probe_host[1])
+    slot = 4 * (int(counter) & 3)                 # the replayed step ran with this counter: its slot of the probe ring
+    walked, total = int(sampler._probe_host[slot]), int(sampler._probe_host[slot + 1])
     return statistics.median(times[1:]), (walked / total if total else None)
 
 

@@ -1,8 +1,8 @@
 """Child process of tests/test_fused_gpu.py::test_ddpm_forward_with_every_non_default_variant: ONE first (uncached)
 and ONE cached forward of the fused network on the shipped DDPM architecture (B = 2, seeded inputs and weights) under
-whatever kernel-selection knobs (PDR_* of include/pdr_hip.h, read once per process) and evaluation variants
+whatever kernel-selection options (PDR_OPTIONS="name=value,..." -> pdr_set_option, applied by the binding) and evaluation variants
 (PDR_FUSED_OPTS, point_diffusion_refinement_amd/pointnet2/fused_network.py) the environment carries; writes both eps.
-    PDR_FUSED_WS=0 python -m tools.variant_check /tmp/eps.pt"""
+    PDR_OPTIONS=fused_ws=0 python -m tools.variant_check /tmp/eps.pt"""
 import os
 import sys
 
