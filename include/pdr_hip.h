@@ -517,6 +517,57 @@ int pdr_embed_select(const float *table, int ldt, int T, const long long *t_dev,
 int pdr_embed_linear(const float *x, int ldx, const float *ts, int ts_stride, const float *freq, int half,
                      const float *W, const float *bias, int B, int K, int N, int act, float *out, int ldo,
                      pdr_stream_t stream);
+/* ---- a chain of per-point layers of one block as ONE launch (the fused per-level block kernel, for the
+ * per-point halves of the deep levels; csrc/point_chain.hip) -------------------------------------------------------------
+ * Replaces, for rows-per-cloud n <= 256, the launch sequence conv -> GroupNorm fold -> conv -> fold -> activation that
+ * evaluates Mlp_plus_t_emb (pointnet2_modules.py:69-174) on per-point rows -- PointnetKnnFPModule's mlp2 (:829-839) --
+ * or the query conv + first score conv of AttentionModule (attention.py:70-82).
+ *   layer l:  y = x_l . Wt + bias                      x_0 = [seg0 | seg1 | seg2] (rows b n + r of plain tensors),
+ *             f = relu_pre ? max(y, 0) : y             x_l = the activated main columns of layer l - 1
+ *             z = GroupNorm(groups, Cn)(f) (gamma != NULL; the first Cn channels are normalised over the n rows of the
+ *                 cloud, the rest pass: MyGroupNorm, pointnet2_modules.py:23-40), relu_post, + add[b, :]
+ *   layer 0 with `residual`: its columns [main_cols, Cout) (the residual conv sharing the input) stay raw and are added
+ *   to the LAST layer's z (Cout - main_cols == the last layer's width); every other layer has main_cols == Cout.
+ *   out (B n, ldo) = z of the last layer.
+ * B clouds x G workgroups (G <= 8, B G <= 256: all resident): a workgroup owns ALL n rows of its cloud for a block of
+ * output columns that is made of whole GroupNorm groups, so statistics, fold and activation are local to it; the
+ * workgroups of a cloud exchange the activated blocks through `scratch` (write-through stores, one counter per cloud in
+ * `sync`, one agent-scope acquire per layer boundary) -- no GroupNorm launch, no partial moments, no grid-wide barrier.
+ * scratch: >= out[1] floats of pdr_point_chain_plan; sync: >= 2 B + 1 ints, ZEROED ONCE by the caller -- the launch leaves
+ * them zero (sync[2 B] != 0 afterwards: a workgroup gave up waiting; never seen, kept so that a fault cannot hang the
+ * device).  Supported: n in {16, 32, 64, 128, 256}, every width a multiple of 16 G with column blocks of whole groups,
+ * 16-byte aligned pointers, leading dimensions multiples of 4; otherwise PDR_EUNSUPPORTED (the caller runs the layers one
+ * by one).  Exact fp32 MFMA (v_mfma_f32_16x16x4_f32); equals the layer-by-layer evaluation up to fp32 summation order. */
+typedef struct {
+  const float *ptr;     /* (B n, ld) */
+  int C, ld;
+} pdr_chain_seg_t;
+typedef struct {
+  const float *Wt;      /* (Cin, ldw) the conv weight transposed, as pdr_fused_layer */
+  const float *bias;    /* (Cout) or NULL */
+  int ldw, Cin, Cout, main_cols;
+  const float *gamma;   /* (>= Cn) GroupNorm weight, NULL = no GroupNorm behind this layer */
+  const float *beta;
+  int groups, Cn;
+  float eps;
+  int relu_pre, relu_post;
+  const float *add;     /* (B, add_ld) row added after the activation (fc(t_emb) / fc_condition rows), or NULL */
+  int add_ld;
+  int reserved_;
+} pdr_chain_layer_t;
+typedef struct {
+  int n_layers, n_seg;
+  pdr_chain_seg_t seg[3];
+  pdr_chain_layer_t layer[4];
+  int residual, ldo;
+  float *out;
+  float *scratch;
+  int *sync;
+} pdr_point_chain_t;
+/* out[0] = G (workgroups per cloud), out[1] = floats of `scratch`, out[2] = ints of `sync`, out[3] = workgroups of the
+ * launch; host logic only (scratch / sync may still be NULL).  Return codes as pdr_point_chain. */
+int pdr_point_chain_plan(const pdr_point_chain_t *chain, int B, int n, long *out);
+int pdr_point_chain(const pdr_point_chain_t *chain, int B, int n, pdr_stream_t stream);
 /* out (B,m,C0+C1) = rows idx (B,m) of the channel-last concatenation [src0 (B,n,C0) | src1 (B,n,C1)] without
  * building it (the `torch.cat([mapped, features], 1)` + gather_operation of pointnet2_with_pcld_condition.py
  * :392-398 and pointnet2_modules.py:243-246 in one launch) */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "pdr_dedup_sort": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "pdr_weighted_moments": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "pdr_patch_rows": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "pdr_point_chain_plan": (_I, [_P, _I, _I, _P]),
+    "pdr_point_chain": (_I, [_P, _I, _I, _P]),
 }
 
 
@@ -95,6 +97,22 @@ class LayerIn(_c.Structure):
                 ("gs1", _P), ("gs2", _P), ("tile_list", _P), ("n_tiles", _P), ("out_rows", _P), ("partial_tpb", _I),
                 ("wmul", _F), ("wrow0", _P), ("patch_values", _P), ("patch_w", _P), ("patch_ld", _I),
                 ("reserved_", _I)]
+class ChainSeg(_c.Structure):
+    _fields_ = [("ptr", _P), ("C", _I), ("ld", _I)]
+
+
+class ChainLayer(_c.Structure):
+    _fields_ = [("Wt", _P), ("bias", _P), ("ldw", _I), ("Cin", _I), ("Cout", _I), ("main_cols", _I), ("gamma", _P),
+                ("beta", _P), ("groups", _I), ("Cn", _I), ("eps", _F), ("relu_pre", _I), ("relu_post", _I), ("add", _P),
+                ("add_ld", _I), ("reserved_", _I)]
+
+
+class PointChain(_c.Structure):
+    """pdr_point_chain_t of include/pdr_hip.h."""
+    _fields_ = [("n_layers", _I), ("n_seg", _I), ("seg", ChainSeg * 3), ("layer", ChainLayer * 4), ("residual", _I),
+                ("ldo", _I), ("out", _P), ("scratch", _P), ("sync", _P)]
+
+
 _lib = None
 ABI_VERSION = 200          # pdr_version() this binding was written against (include/pdr_hip.h version history)
 

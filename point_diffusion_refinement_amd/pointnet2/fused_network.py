@@ -131,6 +131,14 @@ HOIST_LEVEL0_ON_MAIN = True
 # 5-us launches it hides.  Removed.)
 
 
+# Round 6: the per-point chains of the deep levels -- a feature-propagation block's second MLP on <= 256
+# points per cloud -- as ONE launch (pdr_point_chain: a cluster of workgroups per cloud, column blocks of whole GroupNorm
+# groups, so conv -> GroupNorm -> ReLU -> + embedding -> conv -> ... -> + residual needs no fold launch and no partial
+# moments; csrc/point_chain.hip).  False: the layer-by-layer launches (the cross-check of
+# tests/test_fused_gpu.py::test_point_chain_*).
+POINT_CHAINS = True
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -883,6 +891,54 @@ class FusedMlp:
         Y1, part1, tpb1, folded = run_layer(x, self.first, relu_col0=relu0, fold=self.first_fold(x.rpb))
         return self.after_first(Y1, part1, tpb1, x.P, x.B, x.rpb, bank, x, folded=folded)
 
+    def chain(self, x, bank):
+        """The whole MLP on per-point rows as ONE pdr_point_chain launch -> (P, Clast) tensor, or None when the shapes
+        are outside that kernel (the caller then runs __call__ + materialize).  x: Act over plain row-major segments."""
+        if not POINT_CHAINS or x.dd is not None or x.scale is not None or x.add is not None or x.radd is not None or \
+                x.pre_relu or x.post_relu or x.oadd is not None or not 1 <= len(x.segs) <= 3 or \
+                (self.has_res and self.res_col0 is None) or self.extra_col0 != self.first.Cout or \
+                _PRECISION[0] != "f32" or len(self.norms) > 4:
+            return None
+        if any(len(sg) > 5 and sg[5] is not None or sg[4] != 1 for sg in x.segs):
+            return None
+        lib = _lib.load()
+        B, n = x.B, x.rpb
+        ch = _lib.PointChain()
+        ch.n_layers, ch.n_seg = len(self.norms), len(x.segs)
+        for i, (t, off, C, ld, _) in enumerate(sg[:5] for sg in x.segs):
+            ch.seg[i].ptr, ch.seg[i].C, ch.seg[i].ld = _ptr(t, off), C, ld
+        convs = [self.first] + self.rest
+        keep = []
+        for i, (conv, norm) in enumerate(zip(convs, self.norms)):
+            L = ch.layer[i]
+            L.Wt, L.bias, L.ldw, L.Cin, L.Cout = conv.Wt.data_ptr(), conv.bias.data_ptr(), conv.ldw, conv.Cin, conv.Cout
+            L.main_cols = self.C1 if i == 0 else conv.Cout
+            L.gamma, L.beta, L.groups, L.Cn, L.eps = norm.gamma.data_ptr(), norm.beta.data_ptr(), norm.G, norm.Cn, norm.eps
+            L.relu_pre, L.relu_post = 0, 1
+            inj = bank.get(self.inject.get(i))
+            if inj is not None:
+                if inj[1] % 4 != 0:
+                    return None
+                L.add, L.add_ld = _ptr(inj[0], inj[1]), inj[2]
+                keep.append(inj[0])
+        ch.residual = 1 if self.res_col0 is not None else 0
+        plan = (ctypes.c_long * 4)()
+        if lib.pdr_point_chain_plan(ctypes.byref(ch), B, n, plan) != _lib.PDR_OK:
+            return None
+        dev = self.first.Wt.device
+        out = torch.empty((B * n, self.Clast), dtype=torch.float32, device=dev)
+        scratch = torch.empty((max(int(plan[1]), 4),), dtype=torch.float32, device=dev)
+        # the cluster counters: zeroed once, left zero by every launch (one buffer per batch size of this block)
+        sync = self.__dict__.setdefault("_chain_sync", {}).get((B, dev))
+        if sync is None:
+            sync = self._chain_sync[(B, dev)] = torch.zeros((int(plan[2]),), dtype=torch.int32, device=dev)
+        ch.out, ch.ldo, ch.scratch, ch.sync = out.data_ptr(), out.shape[1], scratch.data_ptr(), sync.data_ptr()
+        rc = lib.pdr_point_chain(ctypes.byref(ch), B, n, _stream())
+        if rc == _lib.PDR_EUNSUPPORTED:
+            return None
+        _lib.check(rc, "point_chain")
+        return out
+
     def first_fold(self, rpb):
         """Fold request of the GroupNorm behind the first conv (for whoever launches that conv)."""
         return FoldReq(self.norms[0], self.C1, rpb)
@@ -1506,8 +1562,11 @@ class FusedKnnFP:
         Cs = unknown_feats_cl.shape[2]
         x2 = Act([(interp, 0, self.att.D, interp.shape[1], 1),
                   (xyz4(unknown_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(unknown), 0, 3, 4, 1)], B * n, B, n)
-        h2, _, _, _ = self.mlp2(x2, bank, relu_stats_extra=False)
-        return materialize(h2).view(B, n, -1)
+        out = self.mlp2.chain(x2, bank)                # one launch for the <= 256-point levels (POINT_CHAINS)
+        if out is None:
+            h2, _, _, _ = self.mlp2(x2, bank, relu_stats_extra=False)
+            out = materialize(h2)
+        return out.view(B, n, -1)
 
 
 def act_colmax(act):

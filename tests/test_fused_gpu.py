@@ -1668,3 +1668,204 @@ def test_embed_select_and_step_table(cuda):
         b = fused(x * 0.9, cond, ts=ts, label=label, use_retained_condition_feature=True).clone()
         fused.step_table = None
     assert torch.equal(a, b)
+
+
+# ---- round 6: a chain of per-point layers as ONE launch (pdr_point_chain) ------------------------------
+def _chain_case(seed, B, n, seg_widths, widths, residual, relu_pre, device, with_add=True):
+    """Random chain problem + its float64 evaluation layer by layer (conv -> [ReLU] -> GroupNorm(32 groups) -> [ReLU] ->
+    + add row, residual = extra columns of layer 0 added at the end)."""
+    g = torch.Generator().manual_seed(seed)
+    segs = [torch.randn(B * n, (c + 3) // 4 * 4, generator=g) for c in seg_widths]
+    x = torch.cat([s[:, :c] for s, c in zip(segs, seg_widths)], 1).double()
+    layers, cin, h, res = [], sum(seg_widths), x, None
+    for i, c in enumerate(widths):
+        cout = c + (widths[-1] if (i == 0 and residual) else 0)
+        W = torch.randn(cin, cout, generator=g) / cin ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+        add = torch.randn(B, c + 8, generator=g) if with_add else None
+        cn = c - c % 32                                         # MyGroupNorm: a tail of c % 32 channels passes through
+        y = h @ W.double() + bias.double()
+        if i == 0 and residual:
+            res, y = y[:, c:], y[:, :c]
+        f = y.relu() if relu_pre else y
+        z = f.clone()
+        fn = f[:, :cn].view(B, n, cn).transpose(1, 2)                                      # (B, cn, n)
+        z[:, :cn] = torch.nn.functional.group_norm(fn, 32, gamma[:cn].double(), beta[:cn].double(), 1e-5) \
+            .transpose(1, 2).reshape(B * n, cn)
+        if not relu_pre:
+            z = z.relu()
+        if add is not None:
+            z = z + add[:, :c].double().repeat_interleave(n, 0)
+        layers.append(dict(W=W, bias=bias, gamma=gamma, beta=beta, add=add, cn=cn, cout=cout, c=c))
+        h, cin = z, c
+    if residual:
+        h = h + res
+    return segs, layers, h
+
+
+def _launch_chain(segs, seg_widths, layers, B, n, residual, relu_pre, device):
+    lib = _lib.load()
+    keep = [s.to(device) for s in segs]
+    ch = _lib.PointChain()
+    ch.n_layers, ch.n_seg, ch.residual = len(layers), len(segs), int(residual)
+    for i, (t, c) in enumerate(zip(keep, seg_widths)):
+        ch.seg[i].ptr, ch.seg[i].C, ch.seg[i].ld = t.data_ptr(), c, t.shape[1]
+    for i, Ld in enumerate(layers):
+        L = ch.layer[i]
+        dv = {k: (v.to(device).contiguous() if torch.is_tensor(v) else v) for k, v in Ld.items()}
+        keep.append(dv)
+        L.Wt, L.bias, L.ldw, L.Cin, L.Cout, L.main_cols = dv["W"].data_ptr(), dv["bias"].data_ptr(), dv["cout"], \
+            dv["W"].shape[0], dv["cout"], dv["c"]
+        L.gamma, L.beta, L.groups, L.Cn, L.eps = dv["gamma"].data_ptr(), dv["beta"].data_ptr(), 32, dv["cn"], 1e-5
+        L.relu_pre, L.relu_post = int(relu_pre), int(not relu_pre)
+        if dv["add"] is not None:
+            L.add, L.add_ld = dv["add"].data_ptr(), dv["add"].shape[1]
+    plan = (ctypes.c_long * 4)()
+    rc = lib.pdr_point_chain_plan(ctypes.byref(ch), B, n, plan)
+    if rc != _lib.PDR_OK:
+        return rc, None, None
+    out = torch.full((B * n, layers[-1]["c"] + 4), float("nan"), device=device)
+    scratch = torch.empty(max(int(plan[1]), 4), device=device)
+    sync = torch.zeros(int(plan[2]), dtype=torch.int32, device=device)
+    ch.out, ch.ldo, ch.scratch, ch.sync = out.data_ptr(), out.shape[1], scratch.data_ptr(), sync.data_ptr()
+    outs = []
+    for _ in range(3):                                   # the counters are left zero: launch after launch, same bytes
+        out.fill_(float("nan"))
+        _lib.check(lib.pdr_point_chain(ctypes.byref(ch), B, n, torch.cuda.current_stream().cuda_stream), "point_chain")
+        torch.cuda.synchronize()
+        assert sync.tolist() == [0] * sync.numel(), "cluster counters not restored / a workgroup timed out"
+        outs.append(out[:, :layers[-1]["c"]].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert bool(torch.isnan(out[:, layers[-1]["c"]:]).all())              # nothing written behind the output columns
+    return rc, outs[0], list(plan)
+
+
+@pytest.mark.parametrize("B,n,seg_widths,widths,residual,relu_pre", [
+    (32, 64, (256, 256, 3), (256, 256), True, False),      # the 64-point level's second MLP (fp4: 515 -> 256 -> 256)
+    (32, 256, (128, 256, 3), (256, 256), True, False),     # the 256-point level's (fp3: 387 -> 256 -> 256)
+    (2, 16, (64,), (128, 128, 128), False, False),         # three layers, no residual, 16 rows per cloud
+    (3, 32, (32, 35), (80, 48), True, False),              # no multiple of 8 clouds, an odd segment, pass-through tails
+    (8, 32, (96,), (64, 128), False, True),                # ReLU -> GroupNorm order (attention score nets), 32 rows
+    (5, 64, (40, 3), (256,), False, False),                # one layer: no hand-off at all
+])
+def test_point_chain_matches_float64_layer_by_layer(cuda, B, n, seg_widths, widths, residual, relu_pre):
+    """pdr_point_chain (one launch: column blocks of whole GroupNorm groups per workgroup, activated blocks exchanged
+    inside the launch) against the float64 evaluation of the same chain layer by layer; three launches in a row give
+    identical bytes and leave the cluster counters zero."""
+    segs, layers, want = _chain_case(1000 + n + B, B, n, seg_widths, widths, residual, relu_pre, cuda)
+    rc, got, plan = _launch_chain(segs, seg_widths, layers, B, n, residual, relu_pre, cuda)
+    assert rc == _lib.PDR_OK and plan[0] >= 1 and plan[3] == B * plan[0], (rc, plan)
+    assert bool(torch.isfinite(got).all())
+    assert _rel(got.double().cpu(), want) < 5e-6, _rel(got.double().cpu(), want)
+
+
+def test_point_chain_refuses_what_it_cannot_run(cuda):
+    """Shapes outside the kernel: PDR_EUNSUPPORTED from the plan (the caller runs the layers one by one); argument
+    errors: PDR_EINVAL."""
+    segs, layers, _ = _chain_case(1, 2, 512, (64,), (64, 64), False, False, cuda)
+    assert _launch_chain(segs, (64,), layers, 2, 512, False, False, cuda)[0] == _lib.PDR_EUNSUPPORTED      # rows
+    segs, layers, _ = _chain_case(2, 2, 64, (64,), (96, 96), False, False, cuda)
+    assert _launch_chain(segs, (64,), layers, 2, 64, False, False, cuda)[0] == _lib.PDR_OK                 # G = 2: 48 cols
+    segs, layers, _ = _chain_case(3, 2, 64, (64,), (40, 40), False, False, cuda)
+    layers[0]["cn"] = layers[1]["cn"] = 32
+    assert _launch_chain(segs, (64,), layers, 2, 64, False, False, cuda)[0] == _lib.PDR_EUNSUPPORTED      # 40 columns
+    lib = _lib.load()
+    ch = _lib.PointChain()
+    assert lib.pdr_point_chain(ctypes.byref(ch), 2, 64, None) == _lib.PDR_EINVAL
+
+
+def test_point_chain_under_uneven_load_and_warm_caches(cuda):
+    """The in-launch hand-off under the conditions the guide says hide a missing release / acquire: other kernels
+    running on a second stream (uneven load: late workgroups, busy memory queues) and consumers whose caches are WARM
+    with the previous launch's scratch (every launch reuses it).  200 launches with inputs changing every launch,
+    every output compared with the float64 result of ITS input."""
+    B, n, seg_widths, widths = 32, 64, (256, 256, 3), (256, 256)
+    lib = _lib.load()
+    segs, layers, want = _chain_case(77, B, n, seg_widths, widths, True, False, cuda)
+    keep = [s.to(cuda) for s in segs]
+    ch = _lib.PointChain()
+    ch.n_layers, ch.n_seg, ch.residual = 2, 3, 1
+    for i, (t, c) in enumerate(zip(keep, seg_widths)):
+        ch.seg[i].ptr, ch.seg[i].C, ch.seg[i].ld = t.data_ptr(), c, t.shape[1]
+    dvs = []
+    for i, Ld in enumerate(layers):
+        L = ch.layer[i]
+        dv = {k: (v.to(cuda).contiguous() if torch.is_tensor(v) else v) for k, v in Ld.items()}
+        dvs.append(dv)
+        L.Wt, L.bias, L.ldw, L.Cin, L.Cout, L.main_cols = dv["W"].data_ptr(), dv["bias"].data_ptr(), dv["cout"], \
+            dv["W"].shape[0], dv["cout"], dv["c"]
+        L.gamma, L.beta, L.groups, L.Cn, L.eps, L.relu_post = dv["gamma"].data_ptr(), dv["beta"].data_ptr(), 32, dv["cn"], 1e-5, 1
+        L.add, L.add_ld = dv["add"].data_ptr(), dv["add"].shape[1]
+    plan = (ctypes.c_long * 4)()
+    assert lib.pdr_point_chain_plan(ctypes.byref(ch), B, n, plan) == _lib.PDR_OK
+    out = torch.empty((B * n, 256), device=cuda)
+    scratch = torch.empty(int(plan[1]), device=cuda)
+    sync = torch.zeros(int(plan[2]), dtype=torch.int32, device=cuda)
+    ch.out, ch.ldo, ch.scratch, ch.sync = out.data_ptr(), 256, scratch.data_ptr(), sync.data_ptr()
+    # the chain is affine in nothing useful, so the reference is recomputed per scale on the CPU for a few scales only
+    scales = [1.0, -0.5, 2.0, 0.25]
+    base = [s.clone() for s in keep]
+    wants = []
+    for sc in scales:
+        sg = [(b.cpu() * sc) for b in base]
+        x = torch.cat([s[:, :c] for s, c in zip(sg, seg_widths)], 1).double()
+        h, res = x, None
+        for i, Ld in enumerate(layers):
+            y = h @ Ld["W"].double() + Ld["bias"].double()
+            if i == 0:
+                res, y = y[:, Ld["c"]:], y[:, :Ld["c"]]
+            fn = y.view(B, n, -1).transpose(1, 2)
+            z = torch.nn.functional.group_norm(fn, 32, Ld["gamma"].double(), Ld["beta"].double(), 1e-5).transpose(1, 2) \
+                .reshape(B * n, -1).relu() + Ld["add"][:, :Ld["c"]].double().repeat_interleave(n, 0)
+            h = z
+        wants.append((h + res).float())
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device=cuda)
+    worst = 0.0
+    for it in range(200):
+        sc = scales[it % len(scales)]
+        for k, b in zip(keep, base):
+            torch.mul(b, sc, out=k)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                big = (big @ big).clamp_(-1, 1)            # chip-filling kernels beside the chain launch
+        _lib.check(lib.pdr_point_chain(ctypes.byref(ch), B, n, torch.cuda.current_stream().cuda_stream), "point_chain")
+        got = out.clone()
+        torch.cuda.synchronize()
+        assert sync.tolist() == [0] * sync.numel(), it
+        e = _rel(got.double().cpu(), wants[it % len(scales)].double())
+        worst = max(worst, e)
+        assert e < 2e-5, (it, e)          # (a stale block would be off by O(1); small inputs round at 5e-6)
+
+
+def test_fp_block_second_mlp_as_one_launch_equals_the_layer_launches(cuda, monkeypatch):
+    """The feature-propagation blocks of the 64- / 256-point levels evaluate their second MLP (conv -> GroupNorm -> ReLU ->
+    + t embedding -> conv -> GroupNorm -> ReLU -> + condition embedding -> + residual conv) as ONE pdr_point_chain launch
+    (fused_network.POINT_CHAINS); eps of the full DDPM network with and without it agree to fp32 summation order, and the
+    chain really ran (two launches per cached forward at B = 2: n = 64 and n = 256)."""
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
+    fused = FN.FusedCloudConditionNet(net)
+    x, cond, label = synthetic_batch(2, seed=5, device=cuda)
+    ts = torch.tensor([300.0, 20.0], device=cuda)
+    lib = _lib.load()
+    calls = []
+    real = lib.pdr_point_chain
+
+    class Spy:
+        def __getattr__(self, name):
+            return getattr(lib, name)
+
+        def pdr_point_chain(self, *a):
+            calls.append(a[2])
+            return real(*a)
+    with torch.no_grad():
+        fused(x, cond, ts=ts, label=label, use_retained_condition_feature=True)
+        monkeypatch.setattr(_lib, "_lib", Spy())
+        on = fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True).clone()
+        monkeypatch.setattr(_lib, "_lib", lib)
+        monkeypatch.setattr(FN, "POINT_CHAINS", False)
+        off = fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True).clone()
+    assert sorted(calls) == [64, 256], calls
+    assert _rel(on, off) < 2e-6, _rel(on, off)
