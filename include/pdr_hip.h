@@ -58,8 +58,8 @@ typedef void *pdr_stream_t; /* hipStream_t */
  *   0.2.0 (200)  round 5 grew three signatures without a bump: pdr_reverse_step gained probe_acc / probe_out
  *                before `stream`, pdr_gn_fold gained nvalid_a / tpb_main_a / nvalid_b / tpb_main_b, pdr_layer_in_t gained
  *                wrow0 / wmul / patch_values / patch_ld / patch_w before `reserved_`; round 6: probe_out is a 4-slot ring
- *                (int[16]), pdr_set_option replaces the environment knobs, pdr_point_chain / pdr_point_chain_plan are
- *                new. */
+ *                (int[16]), pdr_set_option replaces the environment knobs, pdr_point_chain / pdr_point_chain_plan /
+ *                pdr_fused_layer_pair are new. */
 int pdr_version(void);
 /* last hip error string seen by this thread after a PDR_ELAUNCH ("" if none) */
 const char *pdr_last_error(void);
@@ -317,6 +317,15 @@ int pdr_fused_layer_plan(const pdr_layer_in_t *in, long P, int Cin, const float 
 int pdr_fused_layer(const pdr_layer_in_t *in, long P, int Cin, const float *Wt, int ldw,
                     const float *bias, int Cout, float *Y, int ldy, float *partial,
                     int relu_col0, pdr_stream_t stream);
+/* pdr_fused_layer over TWO row sets in ONE launch (round 6): (in, Y, partial) = a tile subset (in->tile_list) of 128-row
+ * tiles with plain or ball-gathered sources and no residual; (in2, Y2, partial2) = plain sources, typically with weighted
+ * statistics (wrow0 / wmul) and its rows of `partial` behind the first problem's (partial2 = their first row; one row per
+ * 128 rows of a batch element, in2->partial_tpb rows per batch element).  Same weights, bias, Cout and relu_col0.  A
+ * deduplicated block's per-neighbour launch and per-query launch of one layer become one link of its launch chain; the
+ * values written are those of the two pdr_fused_layer calls.  PDR_EUNSUPPORTED: launch them one by one. */
+int pdr_fused_layer_pair(const pdr_layer_in_t *in, long P, const pdr_layer_in_t *in2, long P2, int Cin, const float *Wt,
+                         int ldw, const float *bias, int Cout, float *Y, int ldy, float *Y2, int ldy2, float *partial,
+                         float *partial2, int relu_col0, pdr_stream_t stream);
 /* pdr_fused_layer in SPLIT-f16 arithmetic (opt-in, never the default): x . w is evaluated as xh wh + xh wl + xl wh
  * with xh = f16(x), xl = f16(x - xh) (same for w) on v_mfma_f32_32x32x16_f16, fp32 accumulation: every operand is
  * held to max(2^-23 |x|, 2^-25) (two 11-bit halves; the MFMA honours the subnormal lo parts), the dropped xl wl term

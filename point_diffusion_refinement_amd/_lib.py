@@ -48,6 +48,7 @@ SIGNATURES = {
     "pdr_fused_layer_variant": (_I, [_I, _I]),
     "pdr_fused_layer_plan": (_I, [_P, _c.c_long, _I, _P, _I, _I, _P, _I, _P]),
     "pdr_fused_layer": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "pdr_fused_layer_pair": (_I, [_P, _c.c_long, _P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P]),
     "pdr_fused_layer_f16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pdr_fused_layer_pool": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "pdr_fused_layer_pool_f16x3": (_I, [_P, _c.c_long, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),

@@ -1210,6 +1210,45 @@ extern "C" int pdr_fused_layer(const pdr_layer_in_t* in, long P, int Cin, const 
   return pdr::check_launch();
 }
 
+// The same layer over TWO row sets in ONE launch (round 6): `in` / Y / partial = the tile subset of a deduplicated block's
+// per-neighbour rows (pdr_layer_in_t.tile_list; plain or ball-gathered sources, no residual), `in2` / Y2 / partial2 = its
+// per-QUERY rows (plain sources, weighted statistics).  Replaces two dependent launches of a block's launch chain by
+// one; the results are those of the two pdr_fused_layer calls, bit for bit (same tiles, same kernels' arithmetic).
+// PDR_EUNSUPPORTED when the pair has no wave-specialised 128-row instantiation: the caller launches them one by one.
+extern "C" int pdr_fused_layer_pair(const pdr_layer_in_t* in, long P, const pdr_layer_in_t* in2, long P2, int Cin,
+                                    const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
+                                    float* Y2, int ldy2, float* partial, float* partial2, int relu_col0,
+                                    pdr_stream_t stream) {
+  if (!Y || !Y2 || !in || !in2) return PDR_EINVAL;
+  LayerPlan pl, pl2;
+  int rc = plan_layer(in, P, Cin, Wt, ldw, Cout, Y, ldy, &pl);
+  if (rc != PDR_OK) return rc;
+  rc = plan_layer(in2, P2, Cin, Wt, ldw, Cout, Y2, ldy2, &pl2);
+  if (rc != PDR_OK) return rc;
+  if (P == 0 || P2 == 0) return PDR_EUNSUPPORTED;
+  if ((partial == nullptr) != (partial2 == nullptr)) return PDR_EINVAL;
+  // the first problem decides the tile shape: a listed launch of 128-row tiles; the second runs on the same tiles
+  // (its batch elements may be shorter than a tile: partial tiles, one row of `partial2` per 128 rows)
+  if (!in->tile_list || !in->n_tiles || pl.t.tm != 128 || !pl.ws || !pl.vec || !pl2.vec || pl.radd || pl2.radd ||
+      pl2.gath || pl.knn || in2->tile_list)
+    return PDR_EUNSUPPORTED;
+  const int tpb2 = (in2->rows_per_batch + 127) / 128;
+  if (in2->partial_tpb > 0 && in2->partial_tpb < tpb2) return PDR_EINVAL;
+  for (int sg = 0; sg < in2->n_seg; ++sg)
+    if (in2->seg[sg].row_div != 1) return PDR_EUNSUPPORTED;
+  pdr::WsTwin tw;
+  tw.in[1] = *in2;
+  tw.Y[1] = Y2;
+  tw.partial[1] = partial2;
+  tw.ldy[1] = ldy2;
+  tw.n_row_tiles[1] = static_cast<int>((P2 / in2->rows_per_batch) * tpb2);
+  tw.gx = 0;
+  if (!pdr::launch_fused_layer_ws_pair(pl.t.id, pl.gath, *in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0,
+                                       static_cast<int>(pl.ntiles), pl.ncol, tw, pdr::as_stream(stream)))
+    return PDR_EUNSUPPORTED;
+  return pdr::check_launch();
+}
+
 // pdr_fused_layer with SPLIT-f16 arithmetic (opt-in): both GEMM operands are split into f16 hi + lo parts and the
 // product is accumulated as xh wh + xh wl + xl wh on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~22 mantissa
 // bits kept).  Wp = weight image of pdr-side packing (see include/pdr_hip.h), nchunks = K-chunks per column block.

@@ -105,11 +105,30 @@ __device__ __forceinline__ int split_off(int r, int g) { return r * 64 + ((g ^ (
 template <int RT, int CT, bool RADD, bool SPLIT>
 constexpr int ws_waves_per_simd() { return (RT * CT == 1 && !RADD && !SPLIT) ? 6 : 4; }
 
-template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool SPLIT = false, bool POOL = false>
+// PAIR (round 6): the launch carries a SECOND problem (pdr::WsTwin: the same layer over the per-query rows of a
+// deduplicated block; plain sources) for its workgroups tw.gx .. gridDim.x - 1 -- one launch instead of two in a chain
+// of dependent launches.  A workgroup belongs to one problem for its whole life; the choice is made once, here.  The
+// gathered instantiation runs the plain second problem through its runtime plain-segment path (f_g false) and the
+// weighted per-row statistics (WSTAT) are compiled in.  PAIR = false: the kernel as it was (tw unused).
+template <int RT, int CT, int WR, int WC, int KC, bool RADD, int GATH = 0, bool SPLIT = false, bool POOL = false,
+          bool PAIR = false>
 __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) void fused_layer_ws_kernel(
-    pdr_layer_in_t in, int Cin, const float* __restrict__ Wt, int ldw,
-    const float* __restrict__ bias, int Cout, float* __restrict__ Y, int ldy,
-    float* __restrict__ partial, int relu_col0, int n_row_tiles, int tile_order, pdr::PoolArgs pool) {
+    pdr_layer_in_t in_a, int Cin, const float* __restrict__ Wt, int ldw,
+    const float* __restrict__ bias, int Cout, float* __restrict__ Y_a, int ldy_a,
+    float* __restrict__ partial_a, int relu_col0, int n_row_tiles_a, int tile_order, pdr::PoolArgs pool,
+    pdr::WsTwin tw) {
+  static_assert(!PAIR || (!RADD && !SPLIT && !POOL && GATH != 2), "paired launches: plain / ball-gathered, no residual");
+  // (readfirstlane: provably uniform for the compiler too -- the selected values feed scalar operands)
+  const int sel = PAIR ? __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) >= tw.gx ? 1 : 0) : 0;
+  const bool second = PAIR && sel != 0;
+  const pdr_layer_in_t& in = PAIR ? tw.in[sel] : in_a;
+  float* const __restrict__ Y = PAIR ? tw.Y[sel] : Y_a;
+  float* const __restrict__ partial = PAIR ? tw.partial[sel] : partial_a;
+  const int ldy = PAIR ? tw.ldy[sel] : ldy_a;
+  const int n_row_tiles = PAIR ? tw.n_row_tiles[sel] : n_row_tiles_a;
+  // workgroup number / workgroups of this problem
+  const int vbx = (PAIR && second) ? static_cast<int>(blockIdx.x) - tw.gx : static_cast<int>(blockIdx.x);
+  const int vnwg = PAIR ? (second ? static_cast<int>(gridDim.x) - tw.gx : tw.gx) : static_cast<int>(gridDim.x);
   // SPLIT: `Wt` points at the packed f16 hi / lo weight image (pack_f16x3 of fused_network.py: per column block and
   // K-chunk one 16-KiB [hi | lo] x [128 cols][64 B] block in exactly the LDS layout), ldw = chunks per column block
   static_assert(WR * WC == 4, "4 consumer waves");
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   //              XCD x owns the clouds x, x + 8, ...: first = blockIdx.x / 8, step = gridDim.x / 8, and local tile l
   //              is tile l % tpb of cloud x + 8 (l / tpb) -- a cloud's gathered table is fetched into ONE L2.
   // Same cost per chunk either way (one division by tpb); no change of which rows a tile holds.
-  const int nwg = static_cast<int>(gridDim.x);
+  const int nwg = vnwg;
   const int nB = n_row_tiles / tpb;
   // (whole groups of 8 clouds only: otherwise some XCDs would own fewer clouds than others)
   //   listed     (in.tile_list, round 4): the launch computes only the row tiles tile_list[0 .. *n_tiles) -- the tiles of
@@ -152,8 +171,8 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   //              written (its rows of Y / partial keep whatever they held).
   const bool listed = in.tile_list != nullptr;                                            // uniform
   const bool xcd_order = !listed && tile_order != 0 && (nwg & 7) == 0 && nB >= 8 && (nB & 7) == 0;   // uniform
-  const int xcd = static_cast<int>(blockIdx.x) & 7;
-  const int tile_first = xcd_order ? static_cast<int>(blockIdx.x) >> 3 : static_cast<int>(blockIdx.x);
+  const int xcd = vbx & 7;
+  const int tile_first = xcd_order ? vbx >> 3 : vbx;
   const int tile_step = xcd_order ? nwg >> 3 : nwg;
   const int tile_limit = listed ? min(*in.n_tiles, n_row_tiles)
                                 : (xcd_order ? ((nB - xcd + 7) >> 3) * tpb : n_row_tiles);   // local tiles of this walk
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     // the APT4 neighbour indices are one vector load: 20 -> 11 vector-memory instructions per thread and tile (the
     // gathered narrow layers are bound by the CU's vector-memory issue, not by bytes or latency).
     constexpr bool ROWQ = GATH != 0;
-    const int gsh_ = GATH ? __builtin_ctz(in.gK) : 0;
+    const int gsh_ = (GATH && in.gK > 0) ? __builtin_ctz(in.gK) : 0;   // (gK = 0: the plain problem of a pair)
     auto prow = [&](int i) __attribute__((always_inline)) -> int { return ROWQ ? APT4 * vr0 + i : vr0 + VSTEP * i; };
     const int ss_ld = in.ss_ld > 0 ? in.ss_ld : Cin;
     const bool has_pre = in.pre_relu != 0, has_add = in.add != nullptr;
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
     float gs1v[KNN ? APT4 : 1], gs2v[KNN ? APT4 : 1];   // per tile: d2 / weight of this thread's positions
     f32x4 Rq1, Rq2;                                      // per chunk: the conv rows of those two channels
     int g_tile = -1, n_tile = -1;
-    const int gsh = GATH ? __builtin_ctz(in.gK) : 0;
+    const int gsh = (GATH && in.gK > 0) ? __builtin_ctz(in.gK) : 0;
     bool Rgath = false;                                // chunk in flight comes from a gathered segment
     // one chunk in registers (plain arrays: as members of a struct one W quad ended up in scratch)
     // RG: the RESIDUAL is a gathered first-conv window (U_res[idx] + V_res: the residual conv of a block whose
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
       const float* ad_b = (in.add ? in.add + static_cast<long>(b) * in.add_ld : k_zeros) + c.cbase + c.ks;
       const bool f_g = GATH && seg.gV != nullptr;               // uniform
       if constexpr (GATH) {
-        if (c.tile != g_tile) {                                  // uniform: first chunk of a tile
+        if (c.tile != g_tile && (!PAIR || in.gidx)) {            // uniform: first chunk of a tile (of a gathered problem)
           off_sg = -1;
           if (GATH == 1 && c.tile == n_tile) {
             // indices prefetched while the previous tile's last chunk was fetched: the dependent
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
           g_tile = c.tile;
         }
         const int nt = c.tile + tile_step;
-        if (GATH == 1 && last_of_tile(c) && nt < tile_limit) {  // uniform: prefetch the next tile's indices
+        if (GATH == 1 && last_of_tile(c) && nt < tile_limit && (!PAIR || in.gidx)) {  // uniform: prefetch the next tile's indices
           const int nlt = row_tile(nt);
           const int nbl = nlt / tpb, ntb = nlt - nbl * tpb;
           const int nb = nbl * cloud_mul + cloud_add;
@@ -719,7 +738,7 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
       const int nvalid = min(TM, rpb - tb * TM);
       // (weighted statistics -- in.wrow0, the per-query launches of a deduplicated block -- take the per-row path below:
       // a few small launches per step; the full-tile path of every other launch stays as it is)
-      constexpr bool WSTAT = GATH == 0;   // (the per-query rows are materialised: the gathered forms stay as they were)
+      constexpr bool WSTAT = GATH == 0 || PAIR;   // (the per-query rows are materialised: the gathered forms stay as they were)
       const bool rows_full = nvalid == TM && !(WSTAT && in.wrow0);   // uniform
       // opaque copies: keep the per-row store offsets from being hoisted out of the chunk loop
       // (64 live 64-bit addresses would spill)
@@ -1086,10 +1105,10 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(ncol));
 #define PDR_WS_K(RT, CT, WR, WC, KC, RA, GA, SP)                                                          \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, RA, GA, SP>), grid, dim3(512), 0, s, in, \
-                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa)
+                     Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa, pdr::WsTwin())
 #define PDR_WS_POOL(RT, CT, WR, WC, KC)                                                                       \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa, pdr::WsTwin())
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   const bool knn_res = in.rseg.gV && in.rseg.g_r1;
@@ -1114,7 +1133,7 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
   if (pool && split) {
 #define PDR_WS_POOL_SPLIT(RT, CT, WR, WC, KC)                                                                  \
   hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, true, true>), grid, dim3(512), 0, s, \
-                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa)
+                     in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, tile_order_eff, pa, pdr::WsTwin())
     if (id == 4) PDR_WS_POOL_SPLIT(2, 2, 2, 2, 32);
     else if (id == 5) PDR_WS_POOL_SPLIT(1, 2, 2, 2, 32);
     else PDR_WS_POOL_SPLIT(1, 2, 4, 1, 32);
@@ -1154,6 +1173,53 @@ bool launch_fused_layer_ws(int id, bool radd, bool gath, const pdr_layer_in_t& i
 #undef PDR_WS_SPLIT
 #undef PDR_WS_K
 #undef PDR_WS_POOL
+}
+
+// One launch for two problems of the same layer (see PAIR above).  Grid: the first problem's persistent workgroups (as
+// launch_fused_layer_ws would size them) followed by the second's.
+bool launch_fused_layer_ws_pair(int id, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt, int ldw,
+                                const float* bias, int Cout, float* Y, int ldy, float* partial, int relu_col0,
+                                int n_row_tiles, int ncol, WsTwin twin, hipStream_t s) {
+  if (!(id == 2 || id == 4 || id == 7 || id == 8)) return false;                 // 128-row tiles
+  if (!fused_layer_ws_supported(id, false, gath, in, Cin)) return false;
+  const pdr_layer_in_t& in2 = twin.in[1];
+  if (!fused_layer_ws_supported(id, false, false, in2, Cin)) return false;
+  bool knn = false;
+  for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
+  if (knn || in.rseg.ptr || in2.rseg.ptr || in2.tile_list || in2.gidx) return false;
+  for (int sg = 0; sg < in2.n_seg; ++sg)
+    if (in2.seg[sg].gV) return false;
+  const long resident = 512;
+  long cap = (resident + ncol - 1) / ncol;
+  long gx1 = n_row_tiles < cap ? n_row_tiles : cap;
+  long gx2 = twin.n_row_tiles[1] < cap ? twin.n_row_tiles[1] : cap;
+  if (gx1 < 1) gx1 = 1;
+  if (gx2 < 1) gx2 = 1;
+  twin.gx = static_cast<int>(gx1);
+  twin.in[0] = in;
+  twin.Y[0] = Y;
+  twin.partial[0] = partial;
+  twin.ldy[0] = ldy;
+  twin.n_row_tiles[0] = n_row_tiles;
+  const dim3 grid(static_cast<unsigned>(gx1 + gx2), static_cast<unsigned>(ncol));
+  const PoolArgs pa = PoolArgs();
+#define PDR_WS_PAIR(RT, CT, WR, WC, KC)                                                                              \
+  do {                                                                                                               \
+    if (gath)                                                                                                        \
+      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 1, false, false, true>), grid, dim3(512), \
+                         0, s, in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, 0, pa, twin);  \
+    else                                                                                                             \
+      hipLaunchKernelGGL((fused_layer_ws_kernel<RT, CT, WR, WC, KC, false, 0, false, false, true>), grid, dim3(512), \
+                         0, s, in, Cin, Wt, ldw, bias, Cout, Y, ldy, partial, relu_col0, n_row_tiles, 0, pa, twin);  \
+  } while (0)
+  switch (id) {
+    case 2: PDR_WS_PAIR(1, 3, 4, 1, 32); return true;
+    case 4: PDR_WS_PAIR(2, 2, 2, 2, 32); return true;
+    case 7: PDR_WS_PAIR(1, 1, 4, 1, 32); return true;
+    case 8: PDR_WS_PAIR(1, 2, 4, 1, 32); return true;
+    default: return false;
+  }
+#undef PDR_WS_PAIR
 }
 
 }  // namespace pdr

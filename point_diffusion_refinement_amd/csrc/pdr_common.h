@@ -60,12 +60,30 @@ struct GatherTwin {
   float wmul;          // weight of the counted rows (K)
 };
 
+// Second problem of a PAIRED wave-specialised launch (fused_layer_ws.hip, round 6): the same layer (weights, bias, output
+// width) over another set of rows -- the per-QUERY rows of a deduplicated block beside the tile subset of its
+// per-neighbour rows -- computed by the workgroups gx .. gridDim.x - 1 of ONE launch instead of a launch of their own.
+struct WsTwin {
+  // [0] = the first problem (a copy of the launch's own arguments), [1] = the second: the kernel indexes these arrays
+  // with a uniform 0 / 1 (a select between two kernel-argument STRUCTS did not survive instruction selection)
+  pdr_layer_in_t in[2];
+  float* Y[2];
+  float* partial[2];
+  int ldy[2], n_row_tiles[2];
+  int gx;               // workgroups (grid.x) of the first problem; 0 = not a paired launch
+};
+
 // fused_layer_ws.hip: wave-specialised layer kernel; false = no instantiation for this tile variant
 bool fused_layer_ws_supported(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin);
 bool launch_fused_layer_ws(int variant, bool radd, bool gath, const pdr_layer_in_t& in, int Cin,
                            const float* Wt, int ldw, const float* bias, int Cout, float* Y, int ldy,
                            float* partial, int relu_col0, int n_row_tiles, int ncol, hipStream_t s,
                            bool split = false, const PoolArgs* pool = nullptr);
+// one launch for (in, Y, partial) and (twin.in, twin.Y, twin.partial): plain or ball-gathered sources without a residual
+// in the first problem, plain sources in the second; false = no paired instantiation for this tile variant
+bool launch_fused_layer_ws_pair(int variant, bool gath, const pdr_layer_in_t& in, int Cin, const float* Wt, int ldw,
+                                const float* bias, int Cout, float* Y, int ldy, float* partial, int relu_col0,
+                                int n_row_tiles, int ncol, WsTwin twin, hipStream_t s);
 
 // ---- DPP wave reductions (wave64, gfx9 row_shr / row_bcast) -------------------
 // After wave_max_*: lane 63 holds the maximum; callers broadcast with readlane.

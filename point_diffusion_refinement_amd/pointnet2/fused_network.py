@@ -137,6 +137,11 @@ HOIST_LEVEL0_ON_MAIN = True
 # moments; csrc/point_chain.hip).  False: the layer-by-layer launches (the cross-check of
 # tests/test_fused_gpu.py::test_point_chain_*).
 POINT_CHAINS = True
+# Round 6: a deduplicated block's per-neighbour launch (tile subset) and per-query launch of one layer as ONE launch
+# (pdr_fused_layer_pair: the second problem's workgroups ride behind the first's) -- a block's launch chain loses a link
+# per layer (plain / ball-gathered sources without a residual: the shared MLP's convs and the key half of the first
+# score conv; the value conv, which adds a gathered residual, stays two launches).  False: one launch each.
+PAIRED_LAUNCHES = True
 
 
 def _stream():
@@ -672,6 +677,39 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
         # per-query launch, whatever tile height that launch picks; else pdr_weighted_moments' groups of 128 rows)
         tmd = lib.pdr_fused_layer_tile_rows(dd.m, conv.Cout)
         tpb = dd.tpb + ((dd.m + tmd - 1) // tmd if twin_stats else dd.tpbd)
+    twin_ok = dd is not None and act.twin is not None
+    if PAIRED_LAUNCHES and twin_ok and (twin_stats or not stats) and stats_into is None and \
+            _PRECISION[0] == "f32" and act.radd is None and conv.__dict__.get("_pair_ok", {}).get((act.rpb, dd.m), True):
+        # ---- both row sets in one launch (128-row tiles for the per-query rows too: their statistics rows follow)
+        tw = act.twin
+        tpb_p = dd.tpb + (dd.m + 127) // 128
+        part_p = torch.empty((act.B * tpb_p, conv.Cout, 2), dtype=torch.float32, device=Y.device) if stats else None
+        act.ptpb = tw.ptpb = tpb_p if stats else 0
+        Yd = torch.empty((tw.P, ldy), dtype=torch.float32, device=Y.device)
+        li, li2 = act.struct(), tw.struct()
+        rc0 = conv.Cout if relu_col0 is None else relu_col0
+        # only where the per-query launch runs on the wave-specialised 128-row tiles anyway (the 1024- / 2048-query
+        # levels): the deep levels' per-query rows have launches of their own size that beat riding on
+        # 128-row tiles by more than the launch they would save (measured: all levels paired 5.78 vs 5.75 ms unpaired)
+        plan = (ctypes.c_int * 8)()
+        ok = lib.pdr_fused_layer_plan(ctypes.byref(li2), tw.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw, conv.Cout,
+                                      Yd.data_ptr(), ldy, plan) == _lib.PDR_OK and plan[0] == 1 and plan[7] == 0 and \
+            plan[1] in (2, 4, 7, 8)
+        rc = _lib.PDR_EUNSUPPORTED if not ok else lib.pdr_fused_layer_pair(ctypes.byref(li), act.P, ctypes.byref(li2), tw.P, conv.Cin, conv.Wt.data_ptr(),
+                                      conv.ldw, conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, Yd.data_ptr(), ldy,
+                                      part_p.data_ptr() if stats else None,
+                                      _ptr(part_p, dd.tpb * conv.Cout * 2) if stats else None, rc0, _stream())
+        tw.ptpb = 0
+        if rc == _lib.PDR_OK:
+            if stats:
+                part_p._sub = (dd.nvalid[0], dd.tpb)
+            Y._twin, Y._dd = Yd, dd
+            if fold is None:
+                return Y, part_p, tpb_p
+            return Y, part_p, tpb_p, fold.launch(part_p, tpb_p, act.B)
+        if rc != _lib.PDR_EUNSUPPORTED:
+            _lib.check(rc, "fused_layer_pair")
+        conv.__dict__.setdefault("_pair_ok", {})[(act.rpb, dd.m)] = False      # (not asked again for this shape)
     partial = partial_ptr = None
     act.ptpb = 0
     if stats_into is not None:

@@ -323,6 +323,9 @@ _VARIANTS = [
     ("dedup_from_256_queries", {"PDR_FUSED_OPTS": "DEDUP_MIN_QUERIES=256"}, False),
     ("decoder_maps_in_place", {"PDR_FUSED_OPTS": "AHEAD_DECODER_MAPS=0"}, False),
     ("level0_decoder_map_on_the_geometry_stream", {"PDR_FUSED_OPTS": "HOIST_LEVEL0_ON_MAIN=0"}, False),
+    # round 6: the paired launches as two launches each (same tiles, same arithmetic), the point chains layer by layer
+    ("one_launch_per_row_set", {"PDR_FUSED_OPTS": "PAIRED_LAUNCHES=0"}, True),    # (same tiles, same kernels' arithmetic)
+    ("point_chains_layer_by_layer", {"PDR_FUSED_OPTS": "POINT_CHAINS=0"}, False),
 ]
 
 
