@@ -76,6 +76,8 @@ const char *pdr_last_error(void);
  *   ws_xcd_order       1     tile order of the layer kernels: 0 plain, 1 XCD-local for the gathered ones, 2 for all
  *   deep_chunks        1     0: the tiny per-point layers of the deep levels on the ordinary tiles (pdr_fused_layer_plan)
  *   deep_ks            1     0: those layers without the K split among a workgroup's waves
+ *   deep_jobs32      256     a layer on 32-row tiles is right-sized when it has at most this many 32 x 128 jobs
+ *   deep_jobs64      512     ... on 64-row tiles: at most this many 64 x 64 jobs
  * pdr_option_name(i): name of option i (0 <= i < number of options), NULL beyond -- lets a binding enumerate them. */
 int pdr_set_option(const char *name, int value);
 int pdr_get_option(const char *name, int *value);

@@ -23,6 +23,8 @@ const OptRow k_opts[pdr::OPT_COUNT] = {
     {"ws_xcd_order", 1, 0, 2},    // tile order: 0 plain, 1 XCD-local for the gathered layer kernels, 2 for all
     {"deep_chunks", 1, 0, 1},     // 0: the tiny per-point layers on the ordinary tiles / 32-channel chunks
     {"deep_ks", 1, 0, 1},         // 0: those layers without the K split among a workgroup's waves
+    {"deep_jobs32", 256, 0, 65536},   // right-sized 32-row-tile launches: at most this many 32 x 128 jobs
+    {"deep_jobs64", 512, 0, 65536},   // right-sized 64-row-tile launches: at most this many 64 x 64 jobs
 };
 std::atomic<int> g_opts[pdr::OPT_COUNT];
 std::atomic<bool> g_opts_init{false};

@@ -1064,8 +1064,8 @@ int plan_layer(const pdr_layer_in_t* in, long P, int Cin, const float* Wt, int l
   // 256 -> 256 26.7 -> 22.0, 512 rows 128 -> 128 17.2 -> 13.6; step 6.03 -> 5.87 ms (profiles/r5_tiny_layers_ab.txt).
   pl->deep = 0;
   if (deep_chunks() && Cin > 64 && !in->tile_list) {
-    if (t.id == 6 && pl->ntiles * pl->ncol <= 256) pl->deep = 6;
-    else if (t.id == 5 && vec && !gath && pl->ntiles * ((Cout + 63) / 64) <= 512) pl->deep = 5;
+    if (t.id == 6 && pl->ntiles * pl->ncol <= pdr::option(pdr::OPT_DEEP_JOBS32)) pl->deep = 6;
+    else if (t.id == 5 && vec && !gath && pl->ntiles * ((Cout + 63) / 64) <= pdr::option(pdr::OPT_DEEP_JOBS64)) pl->deep = 5;
     else if (t.id == 4 && vec && !gath && pl->ntiles * pl->ncol <= 128) pl->deep = 4;
   }
   // <= 4 input channels, nothing to apply on the way in, 16-byte rows on both sides: the thin kernel (statistics

@@ -34,7 +34,7 @@ inline hipStream_t as_stream(pdr_stream_t s) { return reinterpret_cast<hipStream
 // 0.2.0 the library never looks at the environment -- the caller sets them.
 enum Opt {
   OPT_FUSED_WS, OPT_NARROW_KC32, OPT_FPS_WAVE, OPT_FPS_LEAN, OPT_KNN_WAVE, OPT_GN_FOLD_SMALL, OPT_WS_NARROW3,
-  OPT_WS_XCD_ORDER, OPT_DEEP_CHUNKS, OPT_DEEP_KS, OPT_COUNT
+  OPT_WS_XCD_ORDER, OPT_DEEP_CHUNKS, OPT_DEEP_KS, OPT_DEEP_JOBS32, OPT_DEEP_JOBS64, OPT_COUNT
 };
 int option(Opt o);
 

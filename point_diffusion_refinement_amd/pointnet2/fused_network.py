@@ -125,6 +125,12 @@ AHEAD_DECODER_MAPS = True
 # main stream then sits idle until the level-0 sampling is done (0.32 -> 0.57 ms: tools/lab/step_markers.py,
 # MARK_BACK_TO_BACK), and that half needs level-0 coordinates only.  Same box: 6.04 / 6.02 vs 6.09 / 6.10 ms per step.
 HOIST_LEVEL0_ON_MAIN = True
+# Round 6: the same half of the ENCODER's feature-transfer blocks of levels >= 1 on the GEOMETRY stream, each right behind
+# its level's neighbourhoods -- that stream spends most of the first millisecond waiting for the sampling chain, and the
+# half needs that level's coordinates only; the block on the main stream is then its query / score / pooling half.
+# (Round 4 tried this on a stream of its own, a FIFTH one, and lost 0.6 ms: the step's four streams are the device's four
+# hardware queues -- tools/lab/two_batches.py: more queues, or two graphs in flight, serialise --, a fifth shares one.)
+AHEAD_ENCODER_MAPS = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -2088,6 +2094,22 @@ class FusedCloudConditionNet:
                 _PAR["stream"] = saved_par
                 prepared[id(blk)] = (prep, event(side))
 
+        def hoist_encoder_map(l):
+            """side stream, right behind level l's neighbourhoods: the query-independent half of the encoder's
+            feature-transfer block of level l (deduplicated form only: see FPS_STREAM on when hoists pay)."""
+            blk = self.enc_map[l]
+            if not (AHEAD_ENCODER_MAPS and hoist and _dedup_on()) or tables.get(id(blk)) is None:
+                return
+            with torch.cuda.stream(side):
+                if not hoisted[0]:
+                    side.wait_event(ev_emb)
+                    hoisted[0] = True
+                saved_par, _PAR["stream"] = _PAR["stream"], None
+                prep = blk.prepare(l_uvw[l], enc_cl[l], l_xyz[l], bank, subset=False,
+                                   neigh=fm_neigh[fm_key(l, blk)], V2=tables.get(id(blk)))
+                _PAR["stream"] = saved_par
+                prepared[id(blk)] = (prep, event(side))
+
         def geometry_tail():
             """side stream, behind the last level's groupings: the remaining per-query tables and the kNN searches (first
             used by the decoder)."""
@@ -2111,6 +2133,8 @@ class FusedCloudConditionNet:
             group_level(k)
             lv = k + 1
             transfer_level(lv, (self.enc_map[lv],) if lv < nlev else (self.dec_map[lv],))
+            if lv < nlev:
+                hoist_encoder_map(lv)
         if side_tables_on:
             # the decoder's transfer blocks of the inner levels share the encoder's neighbourhoods: their tables
             with torch.cuda.stream(side):

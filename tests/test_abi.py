@@ -135,9 +135,10 @@ def test_options_replace_the_environment_knobs():
     lib = _lib.load()
     names = _lib.option_names()
     assert names == ["fused_ws", "narrow_kc32", "fps_wave", "fps_lean", "knn_wave", "gn_fold_small", "ws_narrow3",
-                     "ws_xcd_order", "deep_chunks", "deep_ks"]
+                     "ws_xcd_order", "deep_chunks", "deep_ks", "deep_jobs32", "deep_jobs64"]
     assert lib.pdr_option_name(len(names)) is None and lib.pdr_option_name(-1) is None
-    assert all(_lib.get_option(n) == 1 for n in names)                          # the defaults
+    defaults = {n: _lib.get_option(n) for n in names}
+    assert all(v == 1 for n, v in defaults.items() if not n.startswith("deep_jobs")) and defaults["deep_jobs32"] == 256
     assert lib.pdr_set_option(b"fps_wave", 3) == _lib.PDR_EINVAL and lib.pdr_set_option(b"fps_wave", -1) == _lib.PDR_EINVAL
     assert lib.pdr_set_option(b"no_such_option", 1) == _lib.PDR_EINVAL and lib.pdr_set_option(None, 1) == _lib.PDR_EINVAL
     assert lib.pdr_get_option(b"fps_wave", None) == _lib.PDR_EINVAL
@@ -151,7 +152,7 @@ def test_options_replace_the_environment_knobs():
         assert lib.pdr_fused_layer_tile_rows(65536, 32) == 256
     finally:
         for n in names:
-            _lib.set_option(n, 1)
+            _lib.set_option(n, defaults[n])
     # no getenv in the shipped library
     out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in out, "libpdr_hip.so imports getenv"

@@ -326,6 +326,7 @@ _VARIANTS = [
     # round 6: the paired launches as two launches each (same tiles, same arithmetic), the point chains layer by layer
     ("one_launch_per_row_set", {"PDR_FUSED_OPTS": "PAIRED_LAUNCHES=0"}, True),    # (same tiles, same kernels' arithmetic)
     ("point_chains_layer_by_layer", {"PDR_FUSED_OPTS": "POINT_CHAINS=0"}, False),
+    ("encoder_maps_in_place", {"PDR_FUSED_OPTS": "AHEAD_ENCODER_MAPS=0"}, False),
 ]
 
 
