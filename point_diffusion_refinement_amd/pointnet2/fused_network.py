@@ -131,6 +131,10 @@ HOIST_LEVEL0_ON_MAIN = True
 # (Round 4 tried this on a stream of its own, a FIFTH one, and lost 0.6 ms: the step's four streams are the device's four
 # hardware queues -- tools/lab/two_batches.py: more queues, or two graphs in flight, serialise --, a fifth shares one.)
 AHEAD_ENCODER_MAPS = True
+# ... and the first SA block's per-source table (the source half of its split first conv: level-0 rows, ready when the
+# first feature-transfer block is) in the main stream's idle window behind that block, ahead of the wait for the level-0
+# sampling -- one 40-us launch less between the end of the sampling chain and the first SA block's output.
+SA0_TABLE_AHEAD = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -1521,7 +1525,9 @@ class FusedGroupedBlock:
                        self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"], sorted_q=sq)
         return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
-    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None):
+    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None, U=None):
+        """U: the per-source table of the first conv (SplitFirstConv.source_table) when the caller made it ahead of
+        time -- it needs the source cloud only, not the queries."""
         B, m, _ = new_xyz.shape
         K = self.nsample
         if not (USE_SPLIT_FIRST and _PAR["stream"] is not None):
@@ -1539,7 +1545,7 @@ class FusedGroupedBlock:
         Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                 self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                 res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
-                                U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K),
+                                U=U if U is not None else self.static_U, V2=V2, fold=self.mlp.first_fold(m * K),
                                 dd=self._plan(idx, counts, B, m, K))
 
         mark("  blk:first_conv_stats_done", True)
@@ -2161,12 +2167,15 @@ class FusedCloudConditionNet:
                     l_uvw[0], dec_cl[0], l_xyz[0], bank, subset=False, neigh=fm_neigh[fm_key(0, self.dec_map[0])],
                     V2=tables.get(id(self.dec_map[0]))), None)
                 _PAR["stream"] = saved_par
+            sa_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
+            U_ahead = None
+            if i == 0 and SA0_TABLE_AHEAD and USE_SPLIT_FIRST and hoist0_main and _PAR["stream"] is not None:
+                U_ahead = sa._make_split(sa_in.shape[2]).source_table(sa_in, l_xyz[i])
             main.wait_event(ev_sa[i])
             mark("main:after_wait_sa%d_geometry" % i)
-            sa_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
             centre = gather_rows(sa_in, sels[i])
             l_feat.append(sa(l_xyz[i], sa_in, l_xyz[i + 1], centre, bank, subset=True, neigh=sa_neigh[i],
-                             V2=tables.get(id(sa))))
+                             V2=tables.get(id(sa)), U=U_ahead))
             mark("main:sa%d_done" % i)
         main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
