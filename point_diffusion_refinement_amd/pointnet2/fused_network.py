@@ -135,6 +135,16 @@ AHEAD_ENCODER_MAPS = True
 # first feature-transfer block is) in the main stream's idle window behind that block, ahead of the wait for the level-0
 # sampling -- one 40-us launch less between the end of the sampling chain and the first SA block's output.
 SA0_TABLE_AHEAD = True
+# The per-source table U = [mapped | features | xyz] . W of the other SA blocks and of every feature-propagation block reads
+# the output of the feature-transfer block in front of it (`mapped`) -- but only in its first 32-128 input channels; the
+# rest (the level's own features and coordinates, 2/3 to 9/10 of the K walk) is ready BEFORE that feature-transfer block
+# runs its query half, during which the blocks' second stream has nothing to do.  The table is therefore built in two
+# launches: U_early = [features | xyz] . W[Cm:] on the second stream beside the feature-transfer block, then
+# U = mapped . W[:Cm] + U_early (an output-side add of the layer kernel) on the critical path -- 40-65-us launches become
+# 15-25-us ones.  Same products, another summation order (1e-6).  MEASURED AND LEFT OFF: 5.69 / 5.70 vs 5.61 / 5.64 ms per
+# step (whole evaluation 8.63 / 8.66 vs 8.53 / 8.53), same box -- the fork / join of the second stream and the second
+# launch cost more than the shorter K walk returns (a dependent launch costs what it costs, whatever its K).
+SPLIT_SOURCE_TABLES = False
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -1219,6 +1229,33 @@ class SplitFirstConv:
         run_layer(u_in, self.U, out=(buf, 0))
         return buf
 
+    def _table_halves(self, Cm):
+        """(late, early) convs of the per-source table split behind its first Cm input channels."""
+        cache = self.__dict__.setdefault("_halves", {})
+        if Cm not in cache:
+            zb = torch.zeros_like(self.U.bias)
+            cache[Cm] = (_RawConv(self.U.Wt[:Cm], self.U.bias, self.U.Cout), _RawConv(self.U.Wt[Cm:], zb, self.U.Cout))
+        return cache[Cm]
+
+    def source_table_early(self, Cm, early_feats_cl, src_xyz):
+        """U_early (B n, ld) = [early features | xyz] . W[Cm:]: the part of source_table() that does not read the first
+        Cm channels of the source features (SPLIT_SOURCE_TABLES)."""
+        B, n, _ = early_feats_cl.shape
+        u_in = Act(feature_segments(early_feats_cl) + [(xyz4(src_xyz), 0, 3, 4, 1)], B * n, B, n)
+        return run_layer(u_in, self._table_halves(Cm)[1])[0]
+
+    def source_table_late(self, late_feats_cl, part):
+        """U = late features . W[:Cm] + U_early, into the block's table buffer (see source_table)."""
+        B, n, Cm = late_feats_cl.shape
+        key = (B * n + 1, _ldy(self.U.Cout))
+        buf = self._tables.get(key)
+        if buf is None:
+            buf = self._tables[key] = torch.zeros(key, dtype=torch.float32, device=part.device)
+        a = Act(feature_segments(late_feats_cl), B * n, B, n)
+        a.oadd = (part, 1)
+        run_layer(a, self._table_halves(Cm)[0], out=(buf, 0))
+        return buf
+
     def query_tables(self, query_xyz, has_v0):
         """[V | V0] (B*m, ld or 2 ld): the per-QUERY half of the conv (coordinates and static weights only)."""
         B, m, _ = query_xyz.shape
@@ -1574,7 +1611,12 @@ class FusedKnnFP:
         self.mlp2 = FusedMlp(fp.mlp2, bank)
         self.split = None
 
-    def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank, knn=None, V2=None):
+    def _make_split(self, C):
+        if self.split is None:
+            self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
+        return self.split
+
+    def __call__(self, unknown, known, unknown_feats_cl, known_feats_cl, bank, knn=None, V2=None, U=None):
         lib = _lib.load()
         B, n, _ = unknown.shape
         n2, C = known.shape[1], known_feats_cl.shape[2]
@@ -1583,10 +1625,9 @@ class FusedKnnFP:
         # native call (normally issued by the geometry prepass on the side stream)
         d2, idx, wgt = knn if knn is not None else _ext.knn_group(unknown, known, K)
         if USE_SPLIT_FIRST:
-            if self.split is None:
-                self.split = SplitFirstConv(self.mlp1.first, C, 'knn')
+            self._make_split(C)
             Y1, part1, tpb1, folded = self.split(
-                known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0, s1=d2, s2=wgt, V2=V2,
+                known_feats_cl, known, unknown, idx, None, K, self.mlp1.extra_col0, s1=d2, s2=wgt, V2=V2, U=U,
                 virtual=USE_VIRTUAL_FIRST and USE_VIRTUAL_KNN,
                 res=(self.mlp1.res_col0, self.mlp1.Clast) if self.mlp1.res_col0 is not None else None,
                 fold=self.mlp1.first_fold(n * K))
@@ -2152,6 +2193,23 @@ class FusedCloudConditionNet:
         for l in range(nlev, 0 if hoist0_main else -1, -1):   # in the order the decoder will ask for them
             hoist_decoder_map(l)
 
+        def table_early(split, Cm, early_feats, src_xyz):
+            """second stream, beside the feature-transfer block that is about to run on the main stream: the part of a
+            block's per-source table that does not need that block's output (SPLIT_SOURCE_TABLES) -> (part, event)."""
+            aux = _PAR["stream"]
+            if not (SPLIT_SOURCE_TABLES and USE_SPLIT_FIRST and aux is not None) or early_feats.shape[2] % 4 != 0:
+                return None
+            aux.wait_event(event(main))
+            with torch.cuda.stream(aux):
+                part = split.source_table_early(Cm, early_feats, src_xyz)
+                return part, event(aux)
+
+        def table_late(split, pending, late_feats):
+            if pending is None:
+                return None
+            main.wait_event(pending[1])
+            return split.source_table_late(late_feats, pending[0])
+
         # ---- feature path ------------------------------------------------------------------------
         main.wait_event(ev_fm[0])
         mark("main:after_wait_first_ball_query")
@@ -2159,6 +2217,8 @@ class FusedCloudConditionNet:
         for i, sa in enumerate(self.sa):
             if i > 0:
                 main.wait_event(ev_fm[i])
+            Cm = self.enc_map[i].att.D                    # width of the feature-transfer block's output
+            pend = table_early(sa._make_split(Cm + l_feat[i].shape[2]), Cm, l_feat[i], l_xyz[i]) if i > 0 else None
             mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])))
             mark("main:enc_map%d_done" % i)
             if i == 0 and hoist0_main and hoist and tables.get(id(self.dec_map[0])) is not None:
@@ -2168,7 +2228,7 @@ class FusedCloudConditionNet:
                     V2=tables.get(id(self.dec_map[0]))), None)
                 _PAR["stream"] = saved_par
             sa_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
-            U_ahead = None
+            U_ahead = table_late(sa.split, pend, mapped)
             if i == 0 and SA0_TABLE_AHEAD and USE_SPLIT_FIRST and hoist0_main and _PAR["stream"] is not None:
                 U_ahead = sa._make_split(sa_in.shape[2]).source_table(sa_in, l_xyz[i])
             main.wait_event(ev_sa[i])
@@ -2179,11 +2239,14 @@ class FusedCloudConditionNet:
             mark("main:sa%d_done" % i)
         main.wait_event(ev_knn)
         for i in range(-1, -(len(self.fp) + 1), -1):
+            Cm = self.dec_map[i].att.D
+            pend = table_early(self.fp[i]._make_split(Cm + l_feat[i].shape[2]), Cm, l_feat[i], l_xyz[i]) \
+                if USE_SPLIT_FIRST else None
             mapped = transfer(self.dec_map[i], i % (nlev + 1), dec_cl, l_feat[i], V2=tables.get(id(self.dec_map[i])))
             fp_in = Cat(mapped, l_feat[i]) if USE_SPLIT_FIRST else torch.cat([mapped, l_feat[i]], dim=2)
             mark("main:dec_map%d_done" % (i % (nlev + 1)))
             l_feat[i - 1] = self.fp[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], fp_in, bank, knn=knn[i],
-                                       V2=tables.get(id(self.fp[i])))
+                                       V2=tables.get(id(self.fp[i])), U=table_late(self.fp[i].split, pend, mapped))
             mark("main:fp%d_done" % (i % (nlev + 1)))
         mapped = transfer(self.dec_map[0], 0, dec_cl, l_feat[0], V2=tables.get(id(self.dec_map[0])))
         Cm, Cf = mapped.shape[2], l_feat[0].shape[2]

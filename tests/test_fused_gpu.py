@@ -327,6 +327,8 @@ _VARIANTS = [
     ("one_launch_per_row_set", {"PDR_FUSED_OPTS": "PAIRED_LAUNCHES=0"}, True),    # (same tiles, same kernels' arithmetic)
     ("point_chains_layer_by_layer", {"PDR_FUSED_OPTS": "POINT_CHAINS=0"}, False),
     ("encoder_maps_in_place", {"PDR_FUSED_OPTS": "AHEAD_ENCODER_MAPS=0"}, False),
+    ("first_sa_table_in_the_block", {"PDR_FUSED_OPTS": "SA0_TABLE_AHEAD=0"}, True),
+    ("source_tables_in_two_launches", {"PDR_FUSED_OPTS": "SPLIT_SOURCE_TABLES=1"}, False),
 ]
 
 
