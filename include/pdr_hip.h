@@ -57,7 +57,7 @@ typedef void *pdr_stream_t; /* hipStream_t */
  *   0.1.0 (100)  rounds 1-4.
  *   0.2.0 (200)  round 5 grew three signatures without a bump: pdr_reverse_step gained probe_acc / probe_out
  *                before `stream`, pdr_gn_fold gained nvalid_a / tpb_main_a / nvalid_b / tpb_main_b, pdr_layer_in_t gained
- *                wrow0 / wmul / patch_values / patch_ld / patch_w before `reserved_`; round 6: probe_out is a 4-slot ring
+ *                wrow0 / wmul / patch_values / patch_ld / patch_w before `reserved_`; round 6: pdr_layer_in_t.oadd_rows, probe_out is a 4-slot ring
  *                (int[16]), pdr_set_option replaces the environment knobs, pdr_point_chain / pdr_point_chain_plan /
  *                pdr_fused_layer_pair are new. */
 int pdr_version(void);
@@ -261,6 +261,10 @@ typedef struct {
   const float *oadd;
   int oadd_ld;
   int oadd_div;         /* power of two */
+  /* (round 6) NULL, or (P / oadd_div) ints: position p adds row oadd_rows[p / oadd_div] of `oadd` instead of row
+   * p / oadd_div -- a block evaluated on SORTED queries reads the per-query term where the query conv wrote it, in the
+   * original query order (no row gather of the query features in front of the query conv) */
+  const int *oadd_rows;
   const float *gs1;     /* (P) per-position scalars of kNN-form gathered sources (see pdr_seg_t.g_r1), or NULL */
   const float *gs2;
   /* A SUBSET of the row tiles (NULL: all of them): the launch computes the row tiles tile_list[0 .. *n_tiles)

@@ -94,7 +94,7 @@ class LayerIn(_c.Structure):
     """pdr_layer_in_t of include/pdr_hip.h."""
     _fields_ = [("n_seg", _I), ("seg", Seg * 4), ("scale", _P), ("shift", _P), ("add", _P), ("rseg", Seg),
                 ("add_ld", _I), ("pre_relu", _I), ("post_relu", _I), ("rows_per_batch", _I), ("gidx", _P),
-                ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I),
+                ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I), ("oadd_rows", _P),
                 ("gs1", _P), ("gs2", _P), ("tile_list", _P), ("n_tiles", _P), ("out_rows", _P), ("partial_tpb", _I),
                 ("wmul", _F), ("wrow0", _P), ("patch_values", _P), ("patch_w", _P), ("patch_ld", _I),
                 ("reserved_", _I)]

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256, 2) void fused_layer_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int rl = min((wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, nvalid - 1);
-            acc[i][j][r] += ob[((row0 + rl) >> osh) * in.oadd_ld];
+            const long oq = (row0 + rl) >> osh;
+            acc[i][j][r] += ob[(in.oadd_rows ? static_cast<long>(in.oadd_rows[oq]) : oq) * in.oadd_ld];
           }
         }
       }

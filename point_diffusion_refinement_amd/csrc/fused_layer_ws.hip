@@ -739,14 +739,16 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
       // (weighted statistics -- in.wrow0, the per-query launches of a deduplicated block -- take the per-row path below:
       // a few small launches per step; the full-tile path of every other launch stays as it is)
       constexpr bool WSTAT = GATH == 0 || PAIR;   // (the per-query rows are materialised: the gathered forms stay as they were)
-      const bool rows_full = nvalid == TM && !(WSTAT && in.wrow0);   // uniform
+      // (a row map of the per-query term with fewer than 32 positions per query -- sixteen dependent index loads per
+      // lane in the full-tile path cost the 80-register instantiations 24 bytes of scratch -- takes the per-row path too)
+      const int osh = in.oadd ? __builtin_ctz(in.oadd_div) : 0;
+      const bool rows_full = nvalid == TM && !(WSTAT && (in.wrow0 || (in.oadd_rows && osh < 5)));   // uniform
       // opaque copies: keep the per-row store offsets from being hoisted out of the chunk loop
       // (64 live 64-bit addresses would spill)
       int il_e = il, hi_e = hi, lane_e = lane;
       asm volatile("" : "+v"(il_e), "+v"(hi_e), "+v"(lane_e));
       long ldy_e = ldy;                       // same for the uniform row offsets (scalar registers)
       asm volatile("" : "+s"(ldy_e));
-      const int osh = in.oadd ? __builtin_ctz(in.oadd_div) : 0;
       if constexpr (POOL) {
         // ---- attention pooling (whole row tiles only: the launcher guarantees rows_per_batch % TM == 0): a
         // 32-row MFMA block holds 32 / K whole queries (K in {8, 16, 32}); for a fixed column a query's K rows sit
@@ -844,7 +846,11 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
               // K >= 32 neighbours per query: a 32-row MFMA tile belongs to ONE query row of `oadd`
 #pragma unroll
               for (int i = 0; i < RT; ++i) {
-                const float v = ob[((row0 + (wr * RT + i) * 32) >> osh) * in.oadd_ld];
+                long oq = (row0 + (wr * RT + i) * 32) >> osh;                // this block's query (uniform)
+                // (row map: not in the kNN-form instantiations -- their blocks are never sorted, and the residual form
+                // has no register to spare)
+                if constexpr (GATH != 2) oq = in.oadd_rows ? static_cast<long>(in.oadd_rows[oq]) : oq;
+                const float v = ob[oq * in.oadd_ld];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += v;
               }
@@ -943,7 +949,13 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
                 const int rl = (wr * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_e;
                 if (rl < nvalid) {
                   float y = acc[i][j][r];
-                  if (ob) y += ob[((row0 + rl) >> osh) * in.oadd_ld];
+                  if (ob) {
+                    long oq = (row0 + rl) >> osh;
+                    // (the row map: plain-source instantiations only -- in the gathered ones its index load cost the
+                    // 80-register forms 24 bytes of scratch; fused_layer_ws_supported sends such a call elsewhere)
+                    if constexpr (WSTAT) oq = in.oadd_rows ? static_cast<long>(in.oadd_rows[oq]) : oq;
+                    y += ob[oq * in.oadd_ld];
+                  }
                   ybase[rl * ldy] = y;
                   if (rl >= wlo) {
                     const float f = relu_stat ? fmaxf(y, 0.0f) : y;
@@ -1033,10 +1045,13 @@ namespace pdr {
 bool fused_layer_ws_supported(int id, bool radd, bool gath, const pdr_layer_in_t& in, int Cin) {
   if (Cin > kMaxCin) return false;   // identity scale / shift / add arrays cover kMaxCin channels
   if (in.wrow0 && gath) return false;   // weighted statistics: the plain-source instantiations (and the uniform kernel)
+  // a row map of the per-query term: gathered instantiations read it per 32-row block only (one query per block)
+  if (in.oadd_rows && gath && (in.oadd_div < 32 || in.rows_per_batch % 128 != 0)) return false;
   if (id == 3 || id == 6 || id > 8) return false;   // 128 x 160 (80 accumulators) and 32-row tiles: uniform-wave kernel
   bool knn = false;
   for (int sg = 0; sg < in.n_seg; ++sg) knn = knn || in.seg[sg].g_r1 != nullptr;
   const bool knn_res = in.rseg.gV && in.rseg.g_r1;
+  if (in.oadd_rows && (knn || knn_res)) return false;   // (no row map in the kNN-form instantiations)
   if (knn) {
     // kNN-form gathered sources: both per-position arrays, both rows on every gathered segment, no empty balls
     if (!gath || radd || !in.gs1 || !in.gs2 || in.gcnt) return false;

@@ -145,6 +145,11 @@ SA0_TABLE_AHEAD = True
 # step (whole evaluation 8.63 / 8.66 vs 8.53 / 8.53), same box -- the fork / join of the second stream and the second
 # launch cost more than the shorter K walk returns (a dependent launch costs what it costs, whatever its K).
 SPLIT_SOURCE_TABLES = False
+# Round 6: a block evaluated on SORTED queries no longer gathers its query features into that order in front of the
+# query conv (one launch on the chain of every feature-transfer / SA block): the query conv and the query half of the
+# first score conv run in the ORIGINAL query order and the per-neighbour launch reads the per-query term through the
+# sorted -> original row map (pdr_layer_in_t.oadd_rows).
+QUERIES_IN_PLACE = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -219,6 +224,7 @@ class Act:
         self.first = None              # the FirstOut the gathered segments come from (fallback: materialise)
         self.ss_ld = 0                 # leading dimension of scale / shift (0 = C)
         self.oadd = None               # (tensor (rows, ld), div): output-side per-query add
+        self.oadd_rows = None          # int32 (P / div): row of `oadd` each query reads (None: its own)
         self.dd = None                 # Dedup plan of the block: the launch walks its tile subset
         self.twin = None               # the same activation over the block's per-QUERY rows (first neighbour only)
         self.wrow0, self.wmul = None, 0.0   # a twin's weighted statistics: rows >= wrow0[b] count, x wmul
@@ -248,6 +254,8 @@ class Act:
         li.ss_ld = self.ss_ld
         if self.oadd is not None:
             li.oadd, li.oadd_ld, li.oadd_div = self.oadd[0].data_ptr(), self.oadd[0].shape[1], self.oadd[1]
+            if self.oadd_rows is not None:
+                li.oadd_rows = self.oadd_rows.data_ptr()
         if self.gidx is not None:
             li.gidx = self.gidx.data_ptr()
             li.gcnt = self.gcnt.data_ptr() if self.gcnt is not None else None
@@ -1064,9 +1072,12 @@ class FusedAttention:
         V, _, _, (vs, vt) = run_layer(h, self.v, fold=FoldReq(self.v_norm, self.D, npoint * K))
         return V, vs, vt
 
-    def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None, sorted_q=None):
+    def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None, sorted_q=None,
+                 query_rows=None):
         """query: (B*npoint, Cq) tensor; h: Act (value input); key = Y1[:, key_col0:key_col0+C2];
-        values: result of self.values(h, ...) when it was evaluated ahead of time."""
+        values: result of self.values(h, ...) when it was evaluated ahead of time.
+        query_rows: int32 (B*npoint) -- `query` is in another row order than the block's positions (QUERIES_IN_PLACE:
+        the original order of a block evaluated on sorted queries): position p's query is row query_rows[p / K]."""
         lib = _lib.load()
         P = B * npoint * K
         first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
@@ -1086,6 +1097,10 @@ class FusedAttention:
             a.oadd = (Z, K)
             if a.twin is not None:
                 a.twin.oadd = (Z, 1)                 # per-query rows: one row per query of Z
+            if query_rows is not None:               # Z is in the ORIGINAL query order: read through the row map
+                a.oadd_rows = query_rows
+                if a.twin is not None:
+                    a.twin.oadd_rows = query_rows
             S1, _, _, (s, t) = run_layer(a, self.w1_k, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
         else:
             a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B,
@@ -1503,6 +1518,11 @@ class FusedGroupedBlock:
             self.split = SplitFirstConv(self.mlp.first, Cs, 'ball', self.with_abs, self.with_centre)
         return self.split
 
+    @staticmethod
+    def _in_place(K):
+        """Sorted queries: the query features stay in their original order (the split query conv reads them there)."""
+        return QUERIES_IN_PLACE and SPLIT_QUERY_CONV and K in (32, 64)     # (one query per 32-row block: oadd_rows)
+
     def prepare_static_source(self, src_xyz, src_feats_cl):
         """The source cloud of this block does not change between reverse steps (retained condition features):
         evaluate its per-source table once per batch, in place when a captured graph already reads the buffer."""
@@ -1556,10 +1576,15 @@ class FusedGroupedBlock:
 
     def finish(self, prep, query_feats_cl):
         B, m, K, sq = prep["B"], prep["m"], prep["K"], prep["sq"]
+        rows = None
         if sq is not None:
-            query_feats_cl = gather_rows(query_feats_cl, sq.perm)
+            if self._in_place(K):
+                rows = sq.perm_rows
+            else:
+                query_feats_cl = gather_rows(query_feats_cl, sq.perm)
         out = self.att(query_feats_cl.reshape(B * m, -1), prep["h"], prep["Y1"], prep["part1"], prep["tpb1"],
-                       self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"], sorted_q=sq)
+                       self.mlp.extra_col0, prep["counts"], B, m, K, values=prep["values"], sorted_q=sq,
+                       query_rows=rows)
         return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
     def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None, U=None):
@@ -1573,9 +1598,13 @@ class FusedGroupedBlock:
         # deep level: first GEMM here, then [MLP + value conv] on the auxiliary stream beside [query / score convs]
         idx, counts = neigh if neigh is not None else self.neighbours(src_xyz, new_xyz)
         sq = self._sorted(idx)
+        rows = None
         if sq is not None:                     # the block's queries in sorted order; its output is put back below
             idx, counts, new_xyz = sq.idx, sq.counts, sq.xyz
-            query_feats_cl = gather_rows(query_feats_cl, sq.perm)
+            if self._in_place(K):
+                rows = sq.perm_rows
+            else:
+                query_feats_cl = gather_rows(query_feats_cl, sq.perm)
         if getattr(V2, "_sq", None) is not sq:
             V2 = None                          # tables of another query order: evaluated in the block instead
         split = self._make_split(src_feats_cl.shape[2])
@@ -1595,7 +1624,7 @@ class FusedGroupedBlock:
             return r
         values = _fork_join(B * m * K, chain_a)
         out = self.att(query_feats_cl.reshape(B * m, -1), None, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K,
-                       values=values, sorted_q=sq)
+                       values=values, sorted_q=sq, query_rows=rows)
         mark("  blk:pool_done", True)
         return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
