@@ -150,6 +150,10 @@ SPLIT_SOURCE_TABLES = False
 # first score conv run in the ORIGINAL query order and the per-neighbour launch reads the per-query term through the
 # sorted -> original row map (pdr_layer_in_t.oadd_rows).
 QUERIES_IN_PLACE = True
+# Round 6: the attention's query conv of an SA / feature-propagation block (it reads the block's query features only) on the
+# blocks' second stream at the head of the block, beside the per-source table and the first conv's statistics pass on the
+# main stream -- it was the first link of the main stream's chain behind them.
+QUERY_CONV_AHEAD = True
 # (Tried: the per-query chain of a stage on a companion stream beside the stage's per-neighbour launch, both feeding the
 # stage's fold.  From the block halves' auxiliary stream -- a fork of a forked stream -- hipStreamEndCapture segfaults
 # (ROCm 7.2); from the main stream only it is slower, 6.90 / 6.93 vs 6.85 ms: the fork / join costs more than the
@@ -535,6 +539,27 @@ FPS_STREAM = True
 # one takes 182 us inside the two-stream step against 145 us alone --: 6.07 / 6.06 vs 6.05 / 6.08 ms per step, same box:
 # what one kernel loses beside its neighbour the neighbour gains.  Not a switch.)
 _PAR = {"stream": None}
+
+
+def _ahead_on_aux(fn):
+    """fn() on the blocks' second stream, behind everything the current stream has issued; returns a thunk that makes
+    the current stream wait for it and yields fn's result (None when there is no second stream)."""
+    aux = _PAR["stream"]
+    if aux is None:
+        return None
+    main = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    aux.wait_event(ev)
+    with torch.cuda.stream(aux):
+        result = fn()
+        done = torch.cuda.Event()
+        done.record(aux)
+
+    def join():
+        main.wait_event(done)
+        return result
+    return join
 
 
 def _fork_join(rows, chain_a):
@@ -1072,8 +1097,12 @@ class FusedAttention:
         V, _, _, (vs, vt) = run_layer(h, self.v, fold=FoldReq(self.v_norm, self.D, npoint * K))
         return V, vs, vt
 
+    def query_conv(self, query, B, npoint):
+        """The query conv and its statistics (the first launch of __call__), for callers that issue it ahead."""
+        return run_layer(plain(query, B, npoint), self.q, stats=True, relu_col0=0)
+
     def __call__(self, query, h, Y1, part1, tpb1, key_col0, counts, B, npoint, K, values=None, sorted_q=None,
-                 query_rows=None):
+                 query_rows=None, q_ahead=None):
         """query: (B*npoint, Cq) tensor; h: Act (value input); key = Y1[:, key_col0:key_col0+C2];
         values: result of self.values(h, ...) when it was evaluated ahead of time.
         query_rows: int32 (B*npoint) -- `query` is in another row order than the block's positions (QUERIES_IN_PLACE:
@@ -1084,9 +1113,12 @@ class FusedAttention:
         # GroupNorm over [q.expand(K) | key]: the q half's moments count K times, the key half's come from the first
         # conv's launch -- both folded at the end of the q conv's launch
         Ct = self.C1 + self.C2
-        q, qpart, qtpb, (s, t) = run_layer(plain(query, B, npoint), self.q, relu_col0=0,
-                                           fold=FoldReq(self.n1, self.C1, npoint * K, mult0=float(K),
-                                                        second=(part1, key_col0, self.C2, tpb1, 1.0)))
+        n1_fold = FoldReq(self.n1, self.C1, npoint * K, mult0=float(K), second=(part1, key_col0, self.C2, tpb1, 1.0))
+        if q_ahead is not None:                      # the query conv was launched ahead (query_conv): join, then fold
+            q, qpart, qtpb = q_ahead() if callable(q_ahead) else q_ahead
+            s, t = n1_fold.launch(qpart, qtpb, B)
+        else:
+            q, qpart, qtpb, (s, t) = run_layer(plain(query, B, npoint), self.q, relu_col0=0, fold=n1_fold)
         if SPLIT_QUERY_CONV and (K & (K - 1)) == 0:
             zq = Act([(q, 0, self.C1, q.shape[1], 1)], B * npoint, B, npoint, scale=s, shift=t, pre_relu=True)
             zq.ss_ld = Ct
@@ -1607,6 +1639,10 @@ class FusedGroupedBlock:
                 query_feats_cl = gather_rows(query_feats_cl, sq.perm)
         if getattr(V2, "_sq", None) is not sq:
             V2 = None                          # tables of another query order: evaluated in the block instead
+        q_ahead = None
+        if QUERY_CONV_AHEAD and SPLIT_QUERY_CONV:
+            qf = query_feats_cl.reshape(B * m, -1)
+            q_ahead = _ahead_on_aux(lambda: self.att.query_conv(qf, B, m))
         split = self._make_split(src_feats_cl.shape[2])
         Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                 self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
@@ -1624,7 +1660,7 @@ class FusedGroupedBlock:
             return r
         values = _fork_join(B * m * K, chain_a)
         out = self.att(query_feats_cl.reshape(B * m, -1), None, Y1, part1, tpb1, self.mlp.extra_col0, counts, B, m, K,
-                       values=values, sorted_q=sq, query_rows=rows)
+                       values=values, sorted_q=sq, query_rows=rows, q_ahead=q_ahead)
         mark("  blk:pool_done", True)
         return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
@@ -1653,6 +1689,10 @@ class FusedKnnFP:
         # squared distances, int32 neighbour indices and group_knn's normalised 1/(d2+1e-8) weights from ONE
         # native call (normally issued by the geometry prepass on the side stream)
         d2, idx, wgt = knn if knn is not None else _ext.knn_group(unknown, known, K)
+        q_ahead = None
+        if USE_SPLIT_FIRST and QUERY_CONV_AHEAD and SPLIT_QUERY_CONV:
+            qf = unknown_feats_cl.reshape(B * n, -1)
+            q_ahead = _ahead_on_aux(lambda: self.att.query_conv(qf, B, n))
         if USE_SPLIT_FIRST:
             self._make_split(C)
             Y1, part1, tpb1, folded = self.split(
@@ -1678,7 +1718,7 @@ class FusedKnnFP:
             h, Y1, part1, tpb1 = self.mlp1(plain(G, B, n * K, C=C + 11), bank)
             values = None
         interp = self.att(unknown_feats_cl.reshape(B * n, -1), h, Y1, part1, tpb1, self.mlp1.extra_col0, None, B, n,
-                          K, values=values)
+                          K, values=values, q_ahead=q_ahead)
         Cs = unknown_feats_cl.shape[2]
         x2 = Act([(interp, 0, self.att.D, interp.shape[1], 1),
                   (xyz4(unknown_feats_cl), 0, Cs, _pad4(Cs), 1), (xyz4(unknown), 0, 3, 4, 1)], B * n, B, n)

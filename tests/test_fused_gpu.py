@@ -330,6 +330,7 @@ _VARIANTS = [
     ("first_sa_table_in_the_block", {"PDR_FUSED_OPTS": "SA0_TABLE_AHEAD=0"}, True),
     ("source_tables_in_two_launches", {"PDR_FUSED_OPTS": "SPLIT_SOURCE_TABLES=1"}, False),
     ("query_features_gathered_into_sorted_order", {"PDR_FUSED_OPTS": "QUERIES_IN_PLACE=0"}, False),
+    ("query_conv_in_its_place", {"PDR_FUSED_OPTS": "QUERY_CONV_AHEAD=0"}, True),
 ]
 
 
