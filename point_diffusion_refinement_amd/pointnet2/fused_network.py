@@ -1619,9 +1619,11 @@ class FusedGroupedBlock:
                        query_rows=rows)
         return out.view(B, m, -1)                 # (rows in the original query order, see FusedAttention)
 
-    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None, U=None):
+    def __call__(self, src_xyz, src_feats_cl, new_xyz, query_feats_cl, bank, subset, neigh=None, V2=None, U=None,
+                 q_ahead=None):
         """U: the per-source table of the first conv (SplitFirstConv.source_table) when the caller made it ahead of
-        time -- it needs the source cloud only, not the queries."""
+        time -- it needs the source cloud only, not the queries.  q_ahead: the attention's query conv when the caller
+        launched it ahead (FusedAttention.query_conv on the ORIGINAL query order: QUERIES_IN_PLACE)."""
         B, m, _ = new_xyz.shape
         K = self.nsample
         if not (USE_SPLIT_FIRST and _PAR["stream"] is not None):
@@ -1639,8 +1641,9 @@ class FusedGroupedBlock:
                 query_feats_cl = gather_rows(query_feats_cl, sq.perm)
         if getattr(V2, "_sq", None) is not sq:
             V2 = None                          # tables of another query order: evaluated in the block instead
-        q_ahead = None
-        if QUERY_CONV_AHEAD and SPLIT_QUERY_CONV:
+        if q_ahead is not None and not (sq is None or rows is not None):
+            q_ahead = None                     # (made on the original order, but this block gathered its queries)
+        if q_ahead is None and QUERY_CONV_AHEAD and SPLIT_QUERY_CONV:
             qf = query_feats_cl.reshape(B * m, -1)
             q_ahead = _ahead_on_aux(lambda: self.att.query_conv(qf, B, m))
         split = self._make_split(src_feats_cl.shape[2])
@@ -2181,13 +2184,14 @@ class FusedCloudConditionNet:
         mark("main:embeddings_done")
         ev_emb = event(main)
 
-        def transfer(blk, l, cl, query, V2=None):
+        def transfer(blk, l, cl, query, V2=None, q_ahead=None):
             if id(blk) in prepared:
                 prep, ev = prepared[id(blk)]
                 if ev is not None:
                     main.wait_event(ev)
                 return blk.finish(prep, query)
-            return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2)
+            return blk(l_uvw[l], cl[l], l_xyz[l], query, bank, subset=False, neigh=fm_neigh[fm_key(l, blk)], V2=V2,
+                       q_ahead=q_ahead)
 
         prepared = {}
         hoist = AHEAD_DECODER_MAPS and USE_SPLIT_FIRST and self.two_streams
@@ -2280,6 +2284,10 @@ class FusedCloudConditionNet:
             return split.source_table_late(late_feats, pending[0])
 
         # ---- feature path ------------------------------------------------------------------------
+        # (the first block's query conv reads x_t only: issued before the wait for the first neighbourhoods)
+        q0 = None
+        if QUERY_CONV_AHEAD and SPLIT_QUERY_CONV and QUERIES_IN_PLACE and USE_SPLIT_FIRST and _PAR["stream"] is not None:
+            q0 = self.enc_map[0].att.query_conv(feat0.reshape(B * N, -1), B, N)
         main.wait_event(ev_fm[0])
         mark("main:after_wait_first_ball_query")
         l_feat = [feat0]
@@ -2288,7 +2296,8 @@ class FusedCloudConditionNet:
                 main.wait_event(ev_fm[i])
             Cm = self.enc_map[i].att.D                    # width of the feature-transfer block's output
             pend = table_early(sa._make_split(Cm + l_feat[i].shape[2]), Cm, l_feat[i], l_xyz[i]) if i > 0 else None
-            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])))
+            mapped = transfer(self.enc_map[i], i, enc_cl, l_feat[i], V2=tables.get(id(self.enc_map[i])),
+                              q_ahead=q0 if i == 0 else None)
             mark("main:enc_map%d_done" % i)
             if i == 0 and hoist0_main and hoist and tables.get(id(self.dec_map[0])) is not None:
                 saved_par, _PAR["stream"] = _PAR["stream"], None
