@@ -19,7 +19,7 @@
 // acquire).  One hand-off per layer boundary instead of two launches + a fold.
 //
 // Geometry: B clouds x G workgroups (G = 8 at B = 32: 256 workgroups, one per CU, a cluster on ONE XCD when B % 8 == 0 --
-// placement is a speed matter only), 256 threads.  A workgroup computes n rows x w columns of every layer
+// placement is a speed matter only), 512 threads: four waves multiply, four stage the next chunk.  A workgroup computes n rows x w columns of every layer
 // (w = Cout / G) with v_mfma_f32_16x16x4_f32 in the TRANSPOSED orientation (weights as the A operand, rows as the B
 // operand): a lane then holds four consecutive channels of one row, i.e. the epilogue stores 16-byte row pieces straight
 // from the accumulators and the moments of a column are an in-lane sum over row tiles + a 16-lane reduction.  Rows and
@@ -71,12 +71,18 @@ struct ChainMem {
 // means nothing -- and dropped at the statistics / the store.  (Per-tile guards inside the multiply loop compiled to
 // a branch and an lgkmcnt(0) around every MFMA: +100 us per launch.)
 template <int NMAX, int RT, int CT>
-__global__ __launch_bounds__(256, 1) void point_chain_kernel(pdr_point_chain_t P, int B, int n, int G, int place) {
+__global__ __launch_bounds__(512, 1) void point_chain_kernel(pdr_point_chain_t P, int B, int n, int G, int place) {
   constexpr int APT = NMAX / 32;                 // float4 of A per thread and chunk
   constexpr int WPT = KC * (MAXW / 4) / 256;     // float4 of W per thread and chunk
   __shared__ ChainMem<NMAX> sm;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Waves 0-3 multiply (and run the epilogue: they own the accumulators), waves 4-7 stage: while chunk c is multiplied
+  // out of one LDS stage the loaders commit chunk c + 1 into the other and issue the loads of chunk c + 2.  (Round-6
+  // first version, every wave doing both in turn: 1,100 cycles of load issue + 960 of LDS writes per chunk next to
+  // 4,500 of MFMAs at 256 rows per cloud -- the CU's vector-memory path moves 64 B per clock, a chunk is 40 KB.)
+  const bool loader = wave >= 4;                 // uniform
+  const int lt = tid & 255;                      // thread number within its role
   // cloud / column block of this workgroup.  place = 1: ids b, b + B, ... of a cloud's cluster (same XCD when B % 8 == 0)
   const int b = place ? static_cast<int>(blockIdx.x) % B : static_cast<int>(blockIdx.x) / G;
   const int g = place ? static_cast<int>(blockIdx.x) / B : static_cast<int>(blockIdx.x) % G;
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(pdr_point_chain_t P
     int wk[WPT], wq[WPT], wg[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int e = tid + 256 * i;
+      const int e = lt + 256 * i;
       wk[i] = e / wtot4;
       wq[i] = e - wk[i] * wtot4;
       const int lc = 4 * wq[i];                                    // local column: [main block | residual block]
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(pdr_point_chain_t P
     int cs = 0, cks = 0, ccb = 0, off_seg = -1;
     unsigned aoff[APT], woff[WPT];
     bool partial = false;                                          // chunk in registers: a segment's last, short chunk
-    const int c4 = tid & 7, r0 = tid >> 3;
+    const int c4 = lt & 7, r0 = lt >> 3;
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
       woff[i] = static_cast<unsigned>(min(wk[i], KC - 1) * L.ldw + wg[i]) * 4u;
@@ -220,63 +226,72 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(pdr_point_chain_t P
       wcolr[j] = min(w_main + 16 * (wc + WC * j) + l16, LDW - 1);
     }
 
-    fetch(0);
-    commit(0);
-    __syncthreads();
-    PDR_CT(1 + 8 * l);
-    for (int c = 0; c < nch; ++c) {
-      const int st = c & 1;
+    // (two loops, one per role, with the same number of barriers: the loaders' chunk registers are not live in the
+    // multiply loop and the operand fragments are not live in the loaders')
+    if (loader) {
+      fetch(0);
+      commit(0);
+      if (nch > 1) fetch(1);
+      __syncthreads();
+      for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) {
+          commit((c & 1) ^ 1);
+          if (c + 2 < nch) fetch(c + 2);
+        }
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();
+      PDR_CT(1 + 8 * l);
+      for (int c = 0; c < nch; ++c) {
+        const int st = c & 1;
 #ifdef PDR_LAB_TRACE
-      if (l == 0 && c < 8) PDR_CT(32 + 4 * c);
+        if (l == 0 && c < 8) PDR_CT(32 + 4 * c);
 #endif
-      if (c + 1 < nch) fetch(c + 1);
-#ifdef PDR_LAB_TRACE
-      if (l == 0 && c < 8) PDR_CT(33 + 4 * c);
-#endif
-      if (first && res_cols > 0) {            // uniform: layer 0 also multiplies its residual column block
+        if (first && res_cols > 0) {            // uniform: layer 0 also multiplies its residual column block
 #pragma unroll
-        for (int k4 = 0; k4 < KC / 4; ++k4) {
-          const int k = 4 * k4 + lq;
-          float xb[RT], wa[CT], war[CT];
+          for (int k4 = 0; k4 < KC / 4; ++k4) {
+            const int k = 4 * k4 + lq;
+            float xb[RT], wa[CT], war[CT];
 #pragma unroll
-          for (int i = 0; i < RT; ++i) xb[i] = sm.As[st][xrow[i]][k];
-#pragma unroll
-          for (int j = 0; j < CT; ++j) {
-            wa[j] = sm.Ws[st][k][wcol[j]];
-            war[j] = sm.Ws[st][k][wcolr[j]];
-          }
-#pragma unroll
-          for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RT; ++i) xb[i] = sm.As[st][xrow[i]][k];
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[i], acc[i][j], 0, 0, 0);
-              res[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(war[j], xb[i], res[i][j], 0, 0, 0);
+              wa[j] = sm.Ws[st][k][wcol[j]];
+              war[j] = sm.Ws[st][k][wcolr[j]];
             }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+              for (int j = 0; j < CT; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[i], acc[i][j], 0, 0, 0);
+                res[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(war[j], xb[i], res[i][j], 0, 0, 0);
+              }
+          }
+        } else {
+#pragma unroll
+          for (int k4 = 0; k4 < KC / 4; ++k4) {
+            const int k = 4 * k4 + lq;
+            float xb[RT], wa[CT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) xb[i] = sm.As[st][xrow[i]][k];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) wa[j] = sm.Ws[st][k][wcol[j]];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+              for (int j = 0; j < CT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[i], acc[i][j], 0, 0, 0);
+          }
         }
-      } else {
-#pragma unroll
-        for (int k4 = 0; k4 < KC / 4; ++k4) {
-          const int k = 4 * k4 + lq;
-          float xb[RT], wa[CT];
-#pragma unroll
-          for (int i = 0; i < RT; ++i) xb[i] = sm.As[st][xrow[i]][k];
-#pragma unroll
-          for (int j = 0; j < CT; ++j) wa[j] = sm.Ws[st][k][wcol[j]];
-#pragma unroll
-          for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[i], acc[i][j], 0, 0, 0);
-        }
+#ifdef PDR_LAB_TRACE
+        if (l == 0 && c < 8) PDR_CT(34 + 4 * c);
+#endif
+        __syncthreads();
+#ifdef PDR_LAB_TRACE
+        if (l == 0 && c < 8) PDR_CT(35 + 4 * c);
+#endif
       }
-#ifdef PDR_LAB_TRACE
-      if (l == 0 && c < 8) PDR_CT(34 + 4 * c);
-#endif
-      if (c + 1 < nch) commit(st ^ 1);
-#ifdef PDR_LAB_TRACE
-      if (l == 0 && c < 8) PDR_CT(35 + 4 * c);
-#endif
-      __syncthreads();
     }
 
     PDR_CT(2 + 8 * l);
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(pdr_point_chain_t P
             s2[r] += __shfl_xor(s2[r], m, 64);
           }
         }
-        if (l16 == 0 && ct < NCTm) {
+        if (!loader && l16 == 0 && ct < NCTm) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             sm.red[wr][16 * ct + 4 * lq + r][0] = static_cast<double>(s1[r]);
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(pdr_point_chain_t P
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
       const int ct = wc + WC * j;
-      if (ct < NCTm) {
+      if (!loader && ct < NCTm) {
         const int lc = 16 * ct + 4 * lq, col = col_main0 + lc;
         f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f}, ad = {0.0f, 0.0f, 0.0f, 0.0f};
         if (L.gamma) {
@@ -542,7 +557,7 @@ extern "C" int pdr_point_chain(const pdr_point_chain_t* p, int B, int n, pdr_str
   const dim3 grid(static_cast<unsigned>(B * pl.G));
   hipStream_t s = pdr::as_stream(stream);
   // instantiations: rows per cloud <= 64 (one row tile per wave) / <= 256 (four); 2 or 4 column tiles per wave
-#define PDR_CHAIN(NM, R, C) hipLaunchKernelGGL((point_chain_kernel<NM, R, C>), grid, dim3(256), 0, s, *p, B, n, pl.G, place)
+#define PDR_CHAIN(NM, R, C) hipLaunchKernelGGL((point_chain_kernel<NM, R, C>), grid, dim3(512), 0, s, *p, B, n, pl.G, place)
   if (n <= 64) {
     if (pl.ct <= 2) PDR_CHAIN(64, 1, 2);
     else PDR_CHAIN(64, 1, 4);
