@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256) void gather_add_kernel(
   const long qbase = (row0 + wr0) / K;                     // exact when ksh >= 0 (row0 + wr0 is a multiple of K)
   const float* Vq = V + qbase * ldv;
   const long v0d = has_em ? V0 - V : 0;                    // elements from V to V0 (same address space)
-  for (int c0 = 0; c0 < Cout; c0 += CW) {
+  // (grid.y > 1, round 6: the column passes of a tile dealt to grid.y workgroups -- a launch of a few hundred tiles with
+  // a wide output (the first conv of the 16- / 64-point levels: 128-512 tiles x 1,100 columns) was a serial walk of five
+  // passes per wave on a half-empty chip)
+  for (int c0 = static_cast<int>(blockIdx.y) * CW; c0 < Cout; c0 += CW * static_cast<int>(gridDim.y)) {
     const int c = c0 + 4 * cl;
     const bool cok = c < Cout;   // row widths are padded to a multiple of 4 in ldu / ldv / ldy
     const int cc = cok ? c : 0;
@@ -606,7 +609,11 @@ static int gather_add_impl(const float* U, int ldu, int n_src, const float* V, c
     nblocks += static_cast<long>(B) * ((mq + 127) / 128);
   }
   if (nblocks >= (1L << 31)) return PDR_EINVAL;
-  const dim3 grid(static_cast<unsigned>(nblocks));
+  // column passes per workgroup: all of them, unless the launch has fewer tiles than the chip holds workgroups
+  const int cw = Cout <= 64 ? 64 : (Cout <= 128 ? 128 : 256);
+  const int passes = (Cout + cw - 1) / cw;
+  const int ncb = (nblocks <= 1024 && passes > 1) ? passes : 1;
+  const dim3 grid(static_cast<unsigned>(nblocks), static_cast<unsigned>(ncb));
 #define PDR_GA_K(LPR, KP, HS)                                                                          \
   hipLaunchKernelGGL((gather_add_kernel<LPR, KP, HS>), grid, dim3(256), 0, st, U, ldu, n_src, V, V0, ldv, idx,  \
                      counts, s1, r1, s2, r2, rows_per_batch, K, Cout, Y, ldy, partial, relu_col0, ycol0, \
