@@ -18,6 +18,8 @@ SHAPES = [  # (rows per batch element, Cin, Cout) at B = 32
     (4096, 512, 512), (16384, 512, 512), (16384, 256, 256),   # steady-state probes (not network shapes)
     (512, 128, 128), (512, 64, 64), (2048, 64, 64), (2048, 128, 128), (512, 256, 256), (128, 512, 512),  # deep levels
     (64, 256, 256), (256, 256, 256), (256, 128, 128), (64, 192, 192), (512, 512, 512), (16, 512, 512),   # 21..26
+    # per-source tables of the deep blocks (few rows, wide outputs): 27..32
+    (16, 643, 1163), (64, 323, 1097), (64, 323, 843), (256, 323, 587), (256, 195, 585), (1024, 163, 427),
 ]
 
 
