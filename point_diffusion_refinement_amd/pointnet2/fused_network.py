@@ -131,6 +131,9 @@ HOIST_LEVEL0_ON_MAIN = True
 # (Round 4 tried this on a stream of its own, a FIFTH one, and lost 0.6 ms: the step's four streams are the device's four
 # hardware queues -- tools/lab/two_batches.py: more queues, or two graphs in flight, serialise --, a fifth shares one.)
 AHEAD_ENCODER_MAPS = True
+# ... also in the step that evaluates every neighbourhood: 8.27 / 8.28 vs 8.31 / 8.31 ms per step, same box (unlike the
+# sampling chain's own stream and the level-0 decoder half on the main stream, which pay only in the deduplicated form)
+AHEAD_ENCODER_MAPS_WHOLE = True
 # ... and the first SA block's per-source table (the source half of its split first conv: level-0 rows, ready when the
 # first feature-transfer block is) in the main stream's idle window behind that block, ahead of the wait for the level-0
 # sampling -- one 40-us launch less between the end of the sampling chain and the first SA block's output.
@@ -2218,7 +2221,8 @@ class FusedCloudConditionNet:
             """side stream, right behind level l's neighbourhoods: the query-independent half of the encoder's
             feature-transfer block of level l (deduplicated form only: see FPS_STREAM on when hoists pay)."""
             blk = self.enc_map[l]
-            if not (AHEAD_ENCODER_MAPS and hoist and _dedup_on()) or tables.get(id(blk)) is None:
+            if not (AHEAD_ENCODER_MAPS and hoist and (_dedup_on() or AHEAD_ENCODER_MAPS_WHOLE)) or \
+                    tables.get(id(blk)) is None:
                 return
             with torch.cuda.stream(side):
                 if not hoisted[0]:
