@@ -1877,3 +1877,48 @@ def test_fp_block_second_mlp_as_one_launch_equals_the_layer_launches(cuda, monke
         off = fused(x * 0.9, cond, ts=ts - 1, label=label, use_retained_condition_feature=True).clone()
     assert sorted(calls) == [64, 256], calls
     assert _rel(on, off) < 2e-6, _rel(on, off)
+
+
+def test_graphed_samplers_without_a_step_table(cuda, monkeypatch):
+    """when the network cannot build the step-embedding table (NATIVE_EMBED off, a t_dim or bank width outside
+    pdr_embed_linear's contract) a sampler's native step must fall back to the per-step embedding chain -- round 5 handed
+    the network a (None, counter) pair and crashed.  Both samplers, graph replay, against the same loops with the table."""
+    from point_diffusion_refinement_amd.pointnet2.configs import DIFFUSION_CONFIG
+    from point_diffusion_refinement_amd.pointnet2.reverse_sampler import GraphedFastSampler
+    torch.manual_seed(0)
+    net = PointNet2CloudCondition(ddpm_pointnet_config()).eval().to(cuda)
+    fused = FN.FusedCloudConditionNet(net)
+    x, cond, label = synthetic_batch(2, seed=9, device=cuda)
+    dh = util.calc_diffusion_hyperparams(**DIFFUSION_CONFIG)
+
+    def run(make):
+        outs = []
+        for native in (True, False):
+            monkeypatch.setattr(FN, "NATIVE_EMBED", native)
+            s = make()
+            torch.manual_seed(3)
+            s.begin((2, 2048, 3), cond, label, x_T=x, start_step=4)
+            assert (s._table() is None) == (not native)
+            outs.append(s.finish())
+        return outs
+    a, b = run(lambda: GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True, neighbourhoods='once'))
+    assert bool(torch.isfinite(b).all()) and _rel(b, a) < 1e-4, _rel(b, a)
+    a, b = run(lambda: GraphedFastSampler(fused, dh, DIFFUSION_CONFIG, length=5, sampling_method='var',
+                                          schedule='quadratic', kappa=0.5, noise='cpu', use_graph=True,
+                                          neighbourhoods='once'))
+    assert bool(torch.isfinite(b).all()) and _rel(b, a) < 1e-4, _rel(b, a)
+
+
+def test_adaptive_sampler_is_reproducible_from_a_seed(cuda):
+    """the per-step choice of the captured form reads the probe of ONE given step (a ring slot tagged with
+    the step counter), not whatever the device has published last: two runs from one seed replay the same forms and
+    give identical bytes, also when the switch flips on the way (a restart on a surface)."""
+    net, fused, dh, x0, cond, label = _surface_sampler_inputs(cuda, 2)
+    outs, forms = [], []
+    for _ in range(2):
+        s = GraphedReverseSampler(fused, dh, noise='cpu', use_graph=True, neighbourhoods='adaptive')
+        torch.manual_seed(11)
+        outs.append(s.sample((2, 2048, 3), cond, label, use_a_precomputed_XT=True, step=8, XT=x0))
+        forms.append(dict(s.mode_counts))
+    assert forms[0] == forms[1], forms
+    assert torch.equal(outs[0], outs[1])
