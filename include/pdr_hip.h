@@ -147,7 +147,12 @@ int pdr_three_interpolate_grad(const float *grad_out, const int *idx,
  *   -> dists (B,n1,K) f32 squared, ascending; idx (B,n1,K) i64;
  *      nn (B,n1,K,3) f32 = y[idx]  (may be NULL: return_nn=False)
  * equal distances: lower index first.  K > n2: trailing slots dist 0, idx -1,
- * nn 0 (pytorch3d pads the same way). */
+ * nn 0 (pytorch3d pads the same way).
+ * (pytorch3d is not vendored by the reference: this order is the builder's contract, not a pin.  Against a
+ * restatement of pytorch3d's published MinK -- replace the current maximum on a strictly smaller key, stable bubble
+ * sort; oracle/pdr_oracle.c pdr_oracle_knn_mink, tests/test_oracle.py -- distances are always identical and indices
+ * are identical on tie-free input and for K = 1; among EXACTLY equal distances MinK returns slot order (replacement
+ * history) instead of index order and may keep another of several points tied at the K-th distance.) */
 int pdr_knn_points(const float *x, const float *y, int B, int n1, int n2, int K,
                    float *dists, int64_t *idx, float *nn, pdr_stream_t stream);
 
