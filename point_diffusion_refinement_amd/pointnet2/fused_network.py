@@ -381,13 +381,28 @@ class SortedQueries:
             self.plan = Dedup(self.idx, self.counts, B, m, K)
 
 
-def act_from(Y, C, P, B, rpb, **kw):
-    """Act over the first C columns of a layer output (with its per-query twin when the layer ran deduplicated)."""
+class LayerOut(tuple):
+    """What run_layer returns: the tuple (Y, partial, tiles_per_batch[, (scale, shift)]) -- callers unpack it -- plus, as
+    explicit attributes, what a DEDUPLICATED layer adds: `twin` (the output of its per-query rows), `dd` (the block's
+    Dedup plan) and `sub` (which rows of `partial` hold something: (valid tiles per cloud, main tiles per cloud), the
+    subset arguments of pdr_gn_fold).  (Rounds 4-5 hung these on the tensors themselves -- `Y._twin`, `partial._sub` --,
+    where a `.view()` or `.contiguous()` would have dropped them without a word.)"""
+
+    def __new__(cls, items, twin=None, dd=None, sub=None):
+        o = super().__new__(cls, items)
+        o.twin, o.dd, o.sub = twin, dd, sub
+        return o
+
+
+def act_from(lo, C, P, B, rpb, **kw):
+    """Act over the first C columns of a layer output (a LayerOut, with its per-query twin when the layer ran
+    deduplicated, or a plain tensor)."""
+    Y = lo[0] if isinstance(lo, LayerOut) else lo
     a = Act([(Y, 0, C, Y.shape[1], 1)], P, B, rpb, **kw)
-    dd = getattr(Y, "_dd", None)
+    dd = lo.dd if isinstance(lo, LayerOut) else None
     if dd is not None:
         a.dd = dd
-        a.twin = _twin_act([(Y._twin, 0, C, Y._twin.shape[1], 1)], dd, B, **kw)
+        a.twin = _twin_act([(lo.twin, 0, C, lo.twin.shape[1], 1)], dd, B, **kw)
     return a
 
 
@@ -413,6 +428,7 @@ class FirstOut:
         self.s1, self.s2, self.r1, self.r2 = s1, s2, r1, r2          # kNN form (r1 / r2: padded conv rows)
         self.materialise = materialise                                # (col0, C) -> (P, pad4(C)) tensor
         self.dd, self.deg = None, None      # Dedup plan + the first conv of the per-query rows (B m, ld), materialised
+        self.sub = None                     # the statistics came from a tile subset: (valid tiles per cloud, main tiles)
 
     @property
     def virtual(self):
@@ -454,6 +470,17 @@ def _pad4(c):
 
 
 _XYZ4 = {}
+# Per-forward registry of what the geometry prepass made for a neighbour-index tensor (keyed by the tensor's id; the
+# entry holds the tensor, so the id cannot be reused within the forward): {"sorted": SortedQueries, "probed": bool}.
+# Cleared with _XYZ4 at the start of a forward.  (Rounds 4-5 hung these on the index tensors as attributes.)
+_GEOM = {}
+
+
+def _geom(idx, create=False):
+    e = _GEOM.get(id(idx))
+    if e is None and create:
+        e = _GEOM[id(idx)] = {"tensor": idx, "sorted": None, "probed": False}
+    return e
 
 
 def xyz4(t):
@@ -697,9 +724,10 @@ class FoldReq:
     def C(self):
         return self.C0 + (self.second[2] if self.second else 0)
 
-    def launch(self, partial, tpb, B):
-        """pdr_gn_fold over this request's statistics -> (scale, shift)."""
-        parts = [(partial, self.col0, self.C0, tpb, self.mult0)] + ([self.second] if self.second else [])
+    def launch(self, partial, tpb, B, sub=None):
+        """pdr_gn_fold over this request's statistics -> (scale, shift).  sub: `partial` was produced by a tile subset
+        (LayerOut.sub); `second` may carry its own as a sixth element."""
+        parts = [(partial, self.col0, self.C0, tpb, self.mult0, sub)] + ([self.second] if self.second else [])
         return self.norm.fold(parts, B, self.C, self.n)
 
 
@@ -757,12 +785,10 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
                                       _ptr(part_p, dd.tpb * conv.Cout * 2) if stats else None, rc0, _stream())
         tw.ptpb = 0
         if rc == _lib.PDR_OK:
-            if stats:
-                part_p._sub = (dd.nvalid[0], dd.tpb)
-            Y._twin, Y._dd = Yd, dd
+            sub = (dd.nvalid[0], dd.tpb) if stats else None
             if fold is None:
-                return Y, part_p, tpb_p
-            return Y, part_p, tpb_p, fold.launch(part_p, tpb_p, act.B)
+                return LayerOut((Y, part_p, tpb_p), twin=Yd, dd=dd, sub=sub)
+            return LayerOut((Y, part_p, tpb_p, fold.launch(part_p, tpb_p, act.B, sub=sub)), twin=Yd, dd=dd, sub=sub)
         if rc != _lib.PDR_EUNSUPPORTED:
             _lib.check(rc, "fused_layer_pair")
         conv.__dict__.setdefault("_pair_ok", {})[(act.rpb, dd.m)] = False      # (not asked again for this shape)
@@ -795,24 +821,26 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
             rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
                                      conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, partial_ptr, rc0, _stream())
         _lib.check(rc, "fused_layer")
+    Yd = sub = None
     if dd is not None and act.twin is not None:
         # the same layer over the per-query rows (first neighbour of every query): its rows stand for the K copies
         # in the skipped tiles -- moments weighted by K there, 0 elsewhere
         if twin_stats:
             # ... computed by that launch itself (pdr_layer_in_t.wrow0 / wmul) into the rows behind the tile subset's;
-            # the fold skips the rows of the tiles the subset skipped (Norm.fold reads `_sub`)
+            # the fold skips the rows of the tiles the subset skipped (LayerOut.sub)
             Yd = run_layer(act.twin, conv, relu_col0=relu_col0, stats_into=(partial, dd.tpb, tpb))[0]
-            partial._sub = (dd.nvalid[0], dd.tpb)
+            sub = (dd.nvalid[0], dd.tpb)
         else:
             saved, act.twin.wrow0 = act.twin.wrow0, None
             Yd = run_layer(act.twin, conv, relu_col0=relu_col0)[0]
             act.twin.wrow0 = saved
             if stats:
                 dd.moments(Yd, conv.Cout, rc0, partial)
-        Y._twin, Y._dd = Yd, dd
+    else:
+        dd = None
     if fold is None:
-        return Y, partial, tpb
-    return Y, partial, tpb, fold.launch(partial, tpb, act.B)
+        return LayerOut((Y, partial, tpb), twin=Yd, dd=dd, sub=sub)
+    return LayerOut((Y, partial, tpb, fold.launch(partial, tpb, act.B, sub=sub)), twin=Yd, dd=dd, sub=sub)
 
 
 def materialize(act):
@@ -835,8 +863,9 @@ class Norm:
         self.gamma, self.beta = gn.weight.detach().contiguous(), gn.bias.detach().contiguous()
 
     def fold(self, parts, B, C, n):
-        """parts: [(partial, col0, ncols, tiles_per_batch, mult)] (one or two) covering C channels in order.
-        Returns (scale, shift) of shape (B, C): GroupNorm folded to y = x * scale + shift."""
+        """parts: [(partial, col0, ncols, tiles_per_batch, mult[, sub])] (one or two) covering C channels in order; sub =
+        the subset information of a partial produced by a tile subset.  Returns (scale, shift) of shape (B, C):
+        GroupNorm folded to y = x * scale + shift."""
         lib = _lib.load()
         dev = self.gamma.device
         assert 1 <= len(parts) <= 2 and sum(p[2] for p in parts) == C
@@ -848,20 +877,20 @@ class Norm:
                 return hit
         scale = torch.empty((B, C), dtype=torch.float32, device=dev)
         shift = torch.empty((B, C), dtype=torch.float32, device=dev)
-        (pa, ca, na, ta, ma) = parts[0]
+        (pa, ca, na, ta, ma), sa = parts[0][:5], (parts[0][5] if len(parts[0]) > 5 else None)
+        sb = None
         if len(parts) == 2:
-            (pb, cb, nb, tb, mb) = parts[1]
+            (pb, cb, nb, tb, mb), sb = parts[1][:5], (parts[1][5] if len(parts[1]) > 5 else None)
             second = (_ptr(pb, 2 * cb), pb.shape[1], tb, nb, float(mb))
         else:
-            pb, second = None, (None, 0, 0, 0, 1.0)
+            second = (None, 0, 0, 0, 1.0)
 
-        def sub(t):
-            # statistics of a tile SUBSET (run_layer / SplitFirstConv tag them): (valid tiles per cloud, main tiles)
-            v = getattr(t, "_sub", None) if t is not None else None
+        def sub(v):
+            # statistics of a tile SUBSET (LayerOut.sub / FirstOut.sub): (valid tiles per cloud, main tiles)
             return (v[0].data_ptr(), v[1]) if v is not None else (None, 0)
         _lib.check(lib.pdr_gn_fold(_ptr(pa, 2 * ca), pa.shape[1], ta, na, float(ma), *second, B, self.Cn, self.G,
                                    float(n), float(self.eps), self.gamma.data_ptr(), self.beta.data_ptr(),
-                                   scale.data_ptr(), shift.data_ptr(), *sub(pa), *sub(pb), _stream()), "gn_fold")
+                                   scale.data_ptr(), shift.data_ptr(), *sub(sa), *sub(sb), _stream()), "gn_fold")
         if LAB_SKIP_FOLD:
             self._lab_fold[(B, C, n)] = (scale, shift)
         return scale, shift
@@ -1041,21 +1070,22 @@ class FusedMlp:
         """Everything behind the first conv, given its output `Y1` (a tensor or a FirstOut) and, when the first
         conv's launch carried it, the fold of the first GroupNorm (`folded` = (scale, shift))."""
         first = Y1 if isinstance(Y1, FirstOut) else FirstOut(Y=Y1)
-        part, tpb = part1, tpb1
+        part, tpb, part_sub = part1, tpb1, first.sub
         cur = first.attach(Act([first.seg(0, self.C1)], P, B, rpb))
         if callable(folded):
             folded = folded()
         for i, norm in enumerate(self.norms):
             C = cur.C
-            scale, shift = folded if folded is not None else norm.fold([(part, 0, C, tpb, 1.0)], B, C, rpb)
+            scale, shift = folded if folded is not None else norm.fold([(part, 0, C, tpb, 1.0, part_sub)], B, C, rpb)
             cur.scale, cur.shift, cur.post_relu = scale, shift, True
             inj = bank.get(self.inject.get(i))
             if inj is not None:
                 cur.add, cur.add_ld = inj[0][:, inj[1]:], inj[2]
             if i < len(self.rest):
-                Y, part, tpb, folded = run_layer(cur, self.rest[i],
-                                                 fold=FoldReq(self.norms[i + 1], self.rest[i].Cout, rpb))
-                cur = act_from(Y, self.rest[i].Cout, P, B, rpb)
+                lo = run_layer(cur, self.rest[i], fold=FoldReq(self.norms[i + 1], self.rest[i].Cout, rpb))
+                _, part, tpb, folded = lo
+                part_sub = lo.sub
+                cur = act_from(lo, self.rest[i].Cout, P, B, rpb)
         if self.has_res:
             if self.res_col0 is not None:
                 cur.radd = first.seg(self.res_col0, self.Clast)
@@ -1094,11 +1124,13 @@ class FusedAttention:
         self.D = self.w2.Cout
 
     def values(self, h, B, npoint, K):
-        """Value half (independent of the query features): value conv + its GroupNorm fold."""
+        """Value half (independent of the query features): value conv + its GroupNorm fold -> (V, scale, shift, twin)."""
         if self.v_norm is None:
-            return run_layer(h, self.v)[0], None, None
-        V, _, _, (vs, vt) = run_layer(h, self.v, fold=FoldReq(self.v_norm, self.D, npoint * K))
-        return V, vs, vt
+            lo = run_layer(h, self.v)
+            return lo[0], None, None, lo.twin
+        lo = run_layer(h, self.v, fold=FoldReq(self.v_norm, self.D, npoint * K))
+        V, _, _, (vs, vt) = lo
+        return V, vs, vt, lo.twin                    # (twin: the per-query value rows of a deduplicated block)
 
     def query_conv(self, query, B, npoint):
         """The query conv and its statistics (the first launch of __call__), for callers that issue it ahead."""
@@ -1116,7 +1148,8 @@ class FusedAttention:
         # GroupNorm over [q.expand(K) | key]: the q half's moments count K times, the key half's come from the first
         # conv's launch -- both folded at the end of the q conv's launch
         Ct = self.C1 + self.C2
-        n1_fold = FoldReq(self.n1, self.C1, npoint * K, mult0=float(K), second=(part1, key_col0, self.C2, tpb1, 1.0))
+        n1_fold = FoldReq(self.n1, self.C1, npoint * K, mult0=float(K),
+                          second=(part1, key_col0, self.C2, tpb1, 1.0, first.sub))
         if q_ahead is not None:                      # the query conv was launched ahead (query_conv): join, then fold
             q, qpart, qtpb = q_ahead() if callable(q_ahead) else q_ahead
             s, t = n1_fold.launch(qpart, qtpb, B)
@@ -1136,21 +1169,23 @@ class FusedAttention:
                 a.oadd_rows = query_rows
                 if a.twin is not None:
                     a.twin.oadd_rows = query_rows
-            S1, _, _, (s, t) = run_layer(a, self.w1_k, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
+            lo1 = run_layer(a, self.w1_k, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
         else:
             a = first.attach(Act([(q, 0, self.C1, q.shape[1], K), first.seg(key_col0, self.C2)], P, B,
                                  npoint * K, scale=s, shift=t, pre_relu=True))
-            S1, _, _, (s, t) = run_layer(a, self.w1, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
+            lo1 = run_layer(a, self.w1, relu_col0=0, fold=FoldReq(self.n2, self.w1.Cout, npoint * K))
+        S1, _, _, (s, t) = lo1
         mark("  blk:main_scores_ready", True)
         score_in = Act([(S1, 0, self.w1.Cout, S1.shape[1], 1)], P, B, npoint * K, scale=s, shift=t, pre_relu=True)
-        dd = getattr(S1, "_dd", None)
+        dd = lo1.dd
         score_in.dd = dd                             # the pooled launch walks the block's tile subset
         # a block evaluated on sorted queries (SortedQueries): the pooled launch and the patch write every query's row
         # at its ORIGINAL place (out_rows); the unfused fallback below pools in sorted order and gathers back
         fused_pool = FUSE_SCORE_POOL and K in (8, 16, 32) and (npoint * K) % 32 == 0 and self.D % 4 == 0
         out_rows = sorted_q.perm_rows if (sorted_q is not None and dd is not None and fused_pool) else None
         # (a callable: the value half runs on another stream; calling it joins that stream into this one)
-        V, vs, vt = values() if callable(values) else (values if values is not None else self.values(h, B, npoint, K))
+        V, vs, vt, Vtwin = values() if callable(values) else \
+            (values if values is not None else self.values(h, B, npoint, K))
         mark("  blk:joined", True)
         out = torch.empty((B * npoint, self.D), dtype=torch.float32, device=V.device)
         cptr = counts.data_ptr() if counts is not None else None
@@ -1160,11 +1195,11 @@ class FusedAttention:
         # written by the pooled launch itself (FUSED_PATCH; a pdr_patch_rows launch behind it before)
         patched = dd is not None and FUSED_PATCH and fused_pool and V.shape[1] % 4 == 0
         if patched:
-            score_in.patch = (V._twin, dd.row_w)
+            score_in.patch = (Vtwin, dd.row_w)
 
         def patch():
             if dd is not None and not patched:
-                Vd = V._twin
+                Vd = Vtwin
                 _lib.check(lib.pdr_patch_rows(Vd.data_ptr(), Vd.shape[1], vsp, vtp, int(self.v_relu),
                                               dd.row_w.data_ptr(), B, npoint, self.D, out.data_ptr(), self.D,
                                               out_rows.data_ptr() if out_rows is not None else None, _stream()),
@@ -1363,7 +1398,7 @@ class SplitFirstConv:
                     B, rpb, K, self.Cout, y, ldy, partial.data_ptr(), relu_col0, ycol0, ycols,
                     dd.tile_valid.data_ptr(), ptpb, dd.idx0.data_ptr(), Yd.data_ptr(), ld, dd.wrow0.data_ptr(),
                     float(K), _stream()), "gather_add_tiles_twin")
-                partial._sub = (dd.nvalid[0], dd.tpb)
+                sub[0] = (dd.nvalid[0], dd.tpb)
                 return Yd
             _lib.check(lib.pdr_gather_add_tiles(*args, dd.tile_valid.data_ptr(), ptpb, _stream()), "gather_add_tiles")
             _lib.check(lib.pdr_gather_add(
@@ -1374,7 +1409,8 @@ class SplitFirstConv:
             return Yd
 
         # (a thunk: the fold is launched by whoever consumes it, i.e. on the stream that runs the rest of the MLP)
-        folded = (lambda: fold.launch(partial, ptpb, B)) if fold is not None else None
+        sub = [None]                                   # set by gather_add: the statistics of a tile subset
+        folded = (lambda: fold.launch(partial, ptpb, B, sub=sub[0])) if fold is not None else None
 
         if not virtual:
             gather_add(Y.data_ptr(), ld, 0, -1)
@@ -1408,6 +1444,7 @@ class SplitFirstConv:
                          r2=self.r2 if s1 is not None else None, materialise=materialise)
         if dd is not None:
             first.dd, first.deg = dd, Yd
+        first.sub = sub[0]
         return first, partial, ptpb, folded
 
 
@@ -1503,15 +1540,15 @@ class FusedGroupedBlock:
             self.__dict__[key] = all(tr(rpb, c) == 128 for c in couts)
         return self.__dict__[key]
 
-    def _plan(self, idx, counts, B, m, K):
-        """The Dedup plan of this block's (sorted) neighbourhoods, or None when the block runs whole.  A plan made
-        earlier for the same index tensor (plan_ahead: on the geometry stream, shared by the encoder / decoder
-        feature-transfer blocks of a level) is reused."""
+    def _plan(self, idx, counts, B, m, K, sq=None):
+        """The Dedup plan of this block's (sorted) neighbourhoods -- `idx` = the sorted index rows of `sq`, the
+        SortedQueries plan_ahead made on the geometry stream (shared by the encoder / decoder feature-transfer blocks
+        of a level) --, or None when the block runs whole."""
         if not self._eligible(idx, m, K):
             return None
         # (only ever the plan of SORTED queries: the weighted statistics and the fold's skipped range rely on a cloud's
         # valid tiles being its first ones -- an index tensor that did not pass plan_ahead runs whole)
-        return getattr(idx, "_plan", None)
+        return sq.plan if (sq is not None and sq.idx is idx) else None
 
     def _shape_ok(self, idx, m, K):
         """This block COULD evaluate its one-point neighbourhoods once (whatever the switches say)."""
@@ -1524,29 +1561,35 @@ class FusedGroupedBlock:
 
     def _sorted(self, idx):
         """The SortedQueries made for this index tensor, when this block evaluates its queries in that order."""
-        return getattr(idx, "_sorted", None) if (_dedup_on() and self.dedup) else None
+        e = _geom(idx)
+        return e["sorted"] if (e is not None and _dedup_on() and self.dedup) else None
 
     def plan_ahead(self, neigh, new_xyz):
         """On the CURRENT stream (the one that produced `neigh`), ahead of the block: the query order and the plan --
         or, in a forward that evaluates every neighbourhood, only the probe count of what a plan would walk."""
         idx, counts = neigh
         B, m, K = idx.shape
+        e = _geom(idx, create=True)
         if self._eligible(idx, m, K):
-            if getattr(idx, "_sorted", None) is None:
-                idx._sorted = SortedQueries(idx, counts, new_xyz)
-            sq = idx._sorted
-            sq.idx._plan = sq.plan                         # (the plan of the sorted arrays, made with them)
-        elif _PROBE[0] is not None and self._shape_ok(idx, m, K) and not getattr(idx, "_probed", False):
+            if e["sorted"] is None:
+                e["sorted"] = SortedQueries(idx, counts, new_xyz)      # (with the plan of the sorted arrays)
+        elif _PROBE[0] is not None and self._shape_ok(idx, m, K) and not e["probed"]:
             _lib.check(_lib.load().pdr_dedup_probe(counts.data_ptr(), B, m, K, _probe_ptr(), _stream()), "dedup_probe")
-            idx._probed = True
+            e["probed"] = True
         return neigh
 
     def side_tables(self, neigh, new_xyz, has_v0):
-        """Per-query tables of the first conv, for the query order the block will use (tagged with it)."""
+        """Per-query tables of the first conv, for the query order the block will use: (tables, that order)."""
         sq = self._sorted(neigh[0])
-        V2 = self.split.query_tables(sq.xyz if sq is not None else new_xyz, has_v0=has_v0)
-        V2._sq = sq
-        return V2
+        return self.split.query_tables(sq.xyz if sq is not None else new_xyz, has_v0=has_v0), sq
+
+    @staticmethod
+    def _tables_for(V2, sq):
+        """The per-query tables a caller handed over, if they were made for THIS query order (side_tables' pair; a bare
+        tensor = made for the original order), else None: the block evaluates them itself."""
+        if isinstance(V2, tuple):
+            return V2[0] if V2[1] is sq else None
+        return V2 if sq is None else None
 
     def _make_split(self, Cs):
         if self.split is None:
@@ -1591,15 +1634,14 @@ class FusedGroupedBlock:
         sq = self._sorted(idx) if USE_SPLIT_FIRST else None
         if sq is not None:                     # the block's queries in sorted order (finish() puts the output back)
             idx, counts, new_xyz = sq.idx, sq.counts, sq.xyz
-        if getattr(V2, "_sq", None) is not sq:
-            V2 = None                          # tables of another query order: evaluated here instead
+        V2 = self._tables_for(V2, sq)          # (tables of another query order: evaluated here instead)
         if USE_SPLIT_FIRST:
             split = self._make_split(src_feats_cl.shape[2])
             Y1, part1, tpb1, folded = split(src_feats_cl, src_xyz, new_xyz, idx, None if subset else counts, K,
                                     self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                     res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
                                     U=self.static_U, V2=V2, fold=self.mlp.first_fold(m * K),
-                                    dd=self._plan(idx, counts, B, m, K))
+                                    dd=self._plan(idx, counts, B, m, K, sq))
             h, Y1, part1, tpb1 = self.mlp.after_first(Y1, part1, tpb1, B * m * K, B, m * K, bank, folded=folded)
         else:
             dense_feats = src_feats_cl.dense() if isinstance(src_feats_cl, Cat) else src_feats_cl
@@ -1642,8 +1684,7 @@ class FusedGroupedBlock:
                 rows = sq.perm_rows
             else:
                 query_feats_cl = gather_rows(query_feats_cl, sq.perm)
-        if getattr(V2, "_sq", None) is not sq:
-            V2 = None                          # tables of another query order: evaluated in the block instead
+        V2 = self._tables_for(V2, sq)          # (tables of another query order: evaluated in the block instead)
         if q_ahead is not None and not (sq is None or rows is not None):
             q_ahead = None                     # (made on the original order, but this block gathered its queries)
         if q_ahead is None and QUERY_CONV_AHEAD and SPLIT_QUERY_CONV:
@@ -1654,7 +1695,7 @@ class FusedGroupedBlock:
                                 self.mlp.extra_col0, virtual=USE_VIRTUAL_FIRST,
                                 res=(self.mlp.res_col0, self.mlp.Clast) if self.mlp.res_col0 is not None else None,
                                 U=U if U is not None else self.static_U, V2=V2, fold=self.mlp.first_fold(m * K),
-                                dd=self._plan(idx, counts, B, m, K))
+                                dd=self._plan(idx, counts, B, m, K, sq))
 
         mark("  blk:first_conv_stats_done", True)
 
@@ -1929,6 +1970,7 @@ class FusedCloudConditionNet:
         # first conv (SplitFirstConv.source_table) is evaluated here, once per batch, not once per step
         with torch.no_grad():
             _XYZ4.clear()
+            _GEOM.clear()
             for i, blk in enumerate(self.enc_map):
                 blk.prepare_static_source(net.l_uvw[i], self.enc_cl[i])
             for i, blk in enumerate(self.dec_map):
@@ -1991,6 +2033,7 @@ class FusedCloudConditionNet:
         try:
             if fresh:
                 _XYZ4.clear()
+                _GEOM.clear()
                 self._condition_branch(condition)
             return self._forward_cached(pointcloud, condition, ts, label)
         finally:
@@ -2095,6 +2138,7 @@ class FusedCloudConditionNet:
         net, hp, bank = self.net, self.net.hparams, self.bank
         B, N, _ = pointcloud.shape
         _XYZ4.clear()
+        _GEOM.clear()
         mark("step:begin")
         xyz = pointcloud[:, :, 0:3].contiguous()
         # scale_factor == 1 (checked at construction): xyz / 1 is xyz, bit for bit -- no division kernel, and the

@@ -218,3 +218,55 @@ def test_plan_reports_right_sized_tiny_layers():
             assert p[0] == 1, p
     assert plan(32, 64, 256, 256, gathered=True)[7] == 0           # gathered sources: the wave-specialised tiles
     assert plan(32, 256, 128, 128, gathered=True)[7] == 0
+
+
+def test_round6_entry_points_validate_their_arguments_without_a_gpu():
+    """pdr_point_chain / pdr_point_chain_plan / pdr_fused_layer_pair: argument errors and unsupported shapes are decided
+    on the host (no launch); the plan reports the cluster size and the scratch a chain needs."""
+    import ctypes as C
+    from point_diffusion_refinement_amd import _lib
+    lib = _lib.load()
+    EINVAL, EUNSUP, OK = _lib.PDR_EINVAL, _lib.PDR_EUNSUPPORTED, _lib.PDR_OK
+
+    def chain(n_layers=2, seg=(64, 64), widths=((128, 256), (128, 128)), residual=1, groups=32, cn=None):
+        ch = _lib.PointChain()
+        ch.n_layers, ch.n_seg, ch.residual = n_layers, 1, residual
+        ch.seg[0].ptr, ch.seg[0].C, ch.seg[0].ld = 0x1000, seg[0], seg[1]
+        cin = seg[0]
+        for i, (main, cout) in enumerate(widths[:n_layers]):
+            L = ch.layer[i]
+            L.Wt, L.bias, L.ldw, L.Cin, L.Cout, L.main_cols = 0x2000, 0x3000, cout, cin, cout, main
+            L.gamma, L.beta, L.groups, L.Cn, L.eps, L.relu_post = 0x4000, 0x5000, groups, cn or main, 1e-5, 1
+            cin = main
+        return ch
+    plan = (C.c_long * 4)()
+    ch = chain()
+    assert lib.pdr_point_chain_plan(C.byref(ch), 32, 64, plan) == OK
+    assert list(plan) == [8, 32 * 64 * 128, 65, 256]                # G, floats of scratch, ints of sync, workgroups
+    assert lib.pdr_point_chain_plan(C.byref(ch), 64, 64, plan) == OK and plan[0] == 4     # B G <= 256
+    assert lib.pdr_point_chain_plan(C.byref(ch), 32, 512, plan) == EUNSUP                  # rows per cloud
+    assert lib.pdr_point_chain_plan(C.byref(ch), 32, 48, plan) == EUNSUP
+    assert lib.pdr_point_chain_plan(C.byref(chain(widths=((120, 248), (128, 128)), cn=96)), 32, 64, plan) == EUNSUP   # 120 columns
+    assert lib.pdr_point_chain_plan(C.byref(chain(widths=((128, 256), (64, 64)))), 32, 64, plan) == EINVAL   # residual width
+    assert lib.pdr_point_chain_plan(C.byref(chain(seg=(64, 62))), 32, 64, plan) == EINVAL                    # ld < C
+    assert lib.pdr_point_chain_plan(C.byref(chain(n_layers=0)), 32, 64, plan) == EINVAL
+    bad = chain()
+    bad.layer[1].Cin = 100
+    assert lib.pdr_point_chain_plan(C.byref(bad), 32, 64, plan) == EINVAL                                     # chain of widths
+    assert lib.pdr_point_chain(C.byref(ch), 32, 64, None) == EINVAL                                           # no out / scratch / sync
+    assert lib.pdr_point_chain(None, 32, 64, None) == EINVAL
+    # paired launch: both problems validated like pdr_fused_layer; a first problem without a tile list is not a pair
+    li, li2 = _lib.LayerIn(), _lib.LayerIn()
+    for x, rpb in ((li, 2048), (li2, 64)):
+        x.n_seg = 1
+        x.seg[0].ptr, x.seg[0].C, x.seg[0].ld, x.seg[0].row_div = 0x1000, 64, 64, 1
+        x.rows_per_batch = rpb
+    args = lambda a, b, P2=128: (C.byref(a), 4096, C.byref(b), P2, 64, 0x2000, 64, None, 64, 0x3000, 64, 0x4000, 64,
+                                 None, None, 64, None)
+    assert lib.pdr_fused_layer_pair(*args(li, li2)) == EUNSUP                  # no tile list
+    assert lib.pdr_fused_layer_pair(*args(li, li2, P2=100)) == EINVAL          # P2 not a multiple of its rows per cloud
+    li.tile_list, li.n_tiles = 0x5000, 0x6000
+    li2.tile_list, li2.n_tiles = 0x5000, 0x6000
+    assert lib.pdr_fused_layer_pair(*args(li, li2)) == EUNSUP                  # a listed second problem
+    assert lib.pdr_fused_layer_pair(None, 4096, C.byref(li2), 128, 64, 0x2000, 64, None, 64, 0x3000, 64, 0x4000, 64, None,
+                                    None, 64, None) == EINVAL

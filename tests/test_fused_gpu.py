@@ -1922,3 +1922,50 @@ def test_adaptive_sampler_is_reproducible_from_a_seed(cuda):
         forms.append(dict(s.mode_counts))
     assert forms[0] == forms[1], forms
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- round 6: row map of the per-query term, paired launches ---------------------------------------------------------
+@pytest.mark.parametrize("rpb,Cin,Cout,K,weighted", [(2048, 32, 32, 32, False), (1024, 64, 128, 32, False),
+                                                     (256, 128, 128, 1, True), (64, 256, 128, 1, True),
+                                                     (16, 128, 64, 1, True), (2048, 41, 64, 1, True)])
+def test_layer_per_query_term_through_a_row_map(cuda, rpb, Cin, Cout, K, weighted):
+    """pdr_layer_in_t.oadd_rows: position p adds row oadd_rows[p / div] of `oadd` -- the same bits as adding row p / div
+    of the rows gathered into that order; 32 positions per query (the per-neighbour launches of a sorted block) and one
+    position per query with weighted statistics (its per-query launches), both kernel families."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    B = 3
+    g = torch.Generator(device=dev).manual_seed(rpb + Cout + K)
+    P, ldx, ldw = B * rpb, (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    X = torch.randn(P, ldx, device=dev, generator=g)
+    Wt = torch.randn(Cin, ldw, device=dev, generator=g) * 0.1
+    bias = torch.randn(Cout, device=dev, generator=g)
+    nq = P // K
+    Z = torch.randn(nq, ldw, device=dev, generator=g)
+    perm = torch.cat([b * (nq // B) + torch.randperm(nq // B, device=dev, generator=g) for b in range(B)]).int()
+    Zg = Z[perm.long()].contiguous()
+    thr = torch.tensor([0, rpb // 3, rpb], dtype=torch.int32, device=dev)
+
+    def run(oadd, rows):
+        li = _lib.LayerIn()
+        li.n_seg = 1
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, ldx, 1
+        li.rows_per_batch = rpb
+        li.oadd, li.oadd_ld, li.oadd_div = oadd.data_ptr(), ldw, K
+        if rows is not None:
+            li.oadd_rows = rows.data_ptr()
+        tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+        tpb = (rpb + tm - 1) // tm
+        if weighted:
+            li.wrow0, li.wmul = thr.data_ptr(), float(32)
+        Y = torch.empty(P, ldw, device=dev)
+        part = torch.empty(B * tpb, Cout, 2, device=dev)
+        _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout, Y.data_ptr(),
+                                       ldw, part.data_ptr(), Cout // 2, st), "layer")
+        torch.cuda.synchronize()
+        return Y[:, :Cout].clone(), part.clone()
+    y0, p0 = run(Zg, None)
+    y1, p1 = run(Z, perm)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    want = X[:, :Cin].double() @ Wt[:, :Cout].double() + bias.double() + Zg[:, :Cout].double().repeat_interleave(K, 0)
+    assert _rel(y1.double(), want) < 2e-5
