@@ -925,6 +925,15 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
           using M0 = std::integral_constant<int, 0>;
           using M1 = std::integral_constant<int, 1>;
           using M2 = std::integral_constant<int, 2>;
+#ifdef PDR_LAB_DIRECT_STORE
+          // lab: the wide tiles' rows leave from the accumulator layout (64 dword stores per wave and tile, two 128-byte
+          // row pieces each) instead of through the LDS transpose
+          if (RT * CT == 4) {
+            if (none_relu) store_tile(M0(), std::false_type());
+            else if (all_relu) store_tile(M1(), std::false_type());
+            else store_tile(M2(), std::false_type());
+          } else
+#endif
           if (wide_store) {
             if (none_relu) store_tile(M0(), std::true_type());
             else if (all_relu) store_tile(M1(), std::true_type());
