@@ -296,7 +296,10 @@ typedef struct {
   const float *patch_values;
   const float *patch_w;
   int patch_ld;
-  int reserved_;
+  /* (the former reserved_ field, 0 = as before) wave-specialised tile shapes without a tile_list: nonzero = the launch
+   * walks its row tiles from the last to the first.  Which rows a tile holds, Y and `partial` do not change -- only the
+   * order in time; a caller alternates it along a chain of layers whose activations exceed the memory-side cache. */
+  int walk_reverse;
 } pdr_layer_in_t;
 
 /* rows per workgroup tile chosen for `rows_per_batch` and `Cout` (256/128/64/32); a batch element is cut

@@ -97,7 +97,7 @@ class LayerIn(_c.Structure):
                 ("gcnt", _P), ("gK", _I), ("ss_ld", _I), ("oadd", _P), ("oadd_ld", _I), ("oadd_div", _I), ("oadd_rows", _P),
                 ("gs1", _P), ("gs2", _P), ("tile_list", _P), ("n_tiles", _P), ("out_rows", _P), ("partial_tpb", _I),
                 ("wmul", _F), ("wrow0", _P), ("patch_values", _P), ("patch_w", _P), ("patch_ld", _I),
-                ("reserved_", _I)]
+                ("walk_reverse", _I)]
 class ChainSeg(_c.Structure):
     _fields_ = [("ptr", _P), ("C", _I), ("ld", _I)]
 

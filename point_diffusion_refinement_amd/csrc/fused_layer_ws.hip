@@ -177,7 +177,13 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
   const int tile_limit = listed ? min(*in.n_tiles, n_row_tiles)
                                 : (xcd_order ? ((nB - xcd + 7) >> 3) * tpb : n_row_tiles);   // local tiles of this walk
   // local tile number -> row tile (listed: one scalar load; the list is a few KB, read by every workgroup)
-  auto row_tile = [&](int l) __attribute__((always_inline)) -> int { return listed ? in.tile_list[l] : l; };
+  //   reversed   (in.walk_reverse, round 6): the same local tiles from the last to the first.  A layer's output is larger
+  //              than the 256-MB memory-side cache at the 524,288-row level; the layer that reads it in the order it
+  //              was written finds none of it there, the one that starts where the writer ended finds the writer's tail.
+  const bool rev = in.walk_reverse != 0 && !listed;                                       // uniform
+  auto row_tile = [&](int l) __attribute__((always_inline)) -> int {
+    return listed ? in.tile_list[l] : (rev ? tile_limit - 1 - l : l);
+  };
   const int ptpb = in.partial_tpb > 0 ? in.partial_tpb : tpb;   // rows of `partial` per batch element
   const int cloud_mul = xcd_order ? 8 : 1, cloud_add = xcd_order ? xcd : 0;
   const int my_tiles = tile_limit > tile_first ? (tile_limit - tile_first + tile_step - 1) / tile_step : 0;

@@ -174,6 +174,15 @@ POINT_CHAINS = True
 # per layer (plain / ball-gathered sources without a residual: the shared MLP's convs and the key half of the first
 # score conv; the value conv, which adds a gathered residual, stays two launches).  False: one launch each.
 PAIRED_LAUNCHES = True
+# True: a layer launch walks its row tiles in the direction OPPOSITE to the launch that wrote its main source
+# (pdr_layer_in_t.walk_reverse).  The activations of the 262,144- / 524,288-row levels (134 / 268 MB per layer) do not
+# survive a launch in the 256-MB memory-side cache when the reader starts where the writer started; read from the end
+# the writer's tail is still there: tools/lab/half_batch.py --zigzag, four plain 128 -> 128 layers + folds alone on the
+# chip, 830 -> 734 us at 524,288 rows, 439 -> 398 at 262,144, same bits.  In the STEP it buys nothing (5.497 vs 5.492 ms,
+# four alternating rounds of 100 steps; whole evaluation 8.50 vs 8.52): the wide launches of a feature-propagation block
+# mostly read GATHERED tables, and between a producer and its consumer the block's other half streams 268 MB through
+# the cache on the second stream (on one stream: 5.59-5.64 with and without).  Off; kept as a variant of the tests.
+ZIGZAG_WALK = False
 
 
 def _stream():
@@ -238,6 +247,19 @@ class Act:
         self.ptpb = 0                  # partial rows per cloud of the launch in flight (run_layer sets it)
         self.patch = None              # pooled launch: (per-query value rows, row weights) of the skipped tiles
 
+    def walk(self):
+        """Direction of a launch over this activation: opposite to the producer of its widest materialised segment
+        (ZIGZAG_WALK); forward when that producer is unknown (a table, an input) or the launch walks a tile list."""
+        if not ZIGZAG_WALK or self.dd is not None:
+            return 0
+        best = None
+        for sg in list(self.segs) + ([self.radd] if self.radd is not None else []):
+            if (len(sg) <= 5 or sg[5] is None) and sg[4] == 1 and (best is None or sg[2] > best[2]):
+                best = sg
+        if best is None:
+            return 0
+        return 1 - _WALK.get(best[0].data_ptr(), 1)
+
     _SHARED = ("scale", "shift", "add", "add_ld", "pre_relu", "post_relu", "ss_ld")
 
     def __setattr__(self, k, v):
@@ -279,6 +301,7 @@ class Act:
         if self.patch is not None:
             Vd, w = self.patch
             li.patch_values, li.patch_ld, li.patch_w = Vd.data_ptr(), Vd.shape[1], w.data_ptr()
+        li.walk_reverse = self.walk()
         return li
 
 
@@ -474,6 +497,8 @@ _XYZ4 = {}
 # entry holds the tensor, so the id cannot be reused within the forward): {"sorted": SortedQueries, "probed": bool}.
 # Cleared with _XYZ4 at the start of a forward.  (Rounds 4-5 hung these on the index tensors as attributes.)
 _GEOM = {}
+# per forward: data_ptr of a layer output -> the direction (0 forward / 1 reversed) its producer walked (ZIGZAG_WALK)
+_WALK = {}
 
 
 def _geom(idx, create=False):
@@ -821,6 +846,7 @@ def run_layer(act, conv, stats=False, relu_col0=None, extra_rows=0, out=None, fo
             rc = lib.pdr_fused_layer(ctypes.byref(li), act.P, conv.Cin, conv.Wt.data_ptr(), conv.ldw,
                                      conv.bias.data_ptr(), conv.Cout, y_ptr, ldy, partial_ptr, rc0, _stream())
         _lib.check(rc, "fused_layer")
+    _WALK[Y.data_ptr()] = li.walk_reverse
     Yd = sub = None
     if dd is not None and act.twin is not None:
         # the same layer over the per-query rows (first neighbour of every query): its rows stand for the K copies
@@ -1971,6 +1997,7 @@ class FusedCloudConditionNet:
         with torch.no_grad():
             _XYZ4.clear()
             _GEOM.clear()
+            _WALK.clear()
             for i, blk in enumerate(self.enc_map):
                 blk.prepare_static_source(net.l_uvw[i], self.enc_cl[i])
             for i, blk in enumerate(self.dec_map):
@@ -2034,6 +2061,7 @@ class FusedCloudConditionNet:
             if fresh:
                 _XYZ4.clear()
                 _GEOM.clear()
+                _WALK.clear()
                 self._condition_branch(condition)
             return self._forward_cached(pointcloud, condition, ts, label)
         finally:
@@ -2139,6 +2167,7 @@ class FusedCloudConditionNet:
         B, N, _ = pointcloud.shape
         _XYZ4.clear()
         _GEOM.clear()
+        _WALK.clear()
         mark("step:begin")
         xyz = pointcloud[:, :, 0:3].contiguous()
         # scale_factor == 1 (checked at construction): xyz / 1 is xyz, bit for bit -- no division kernel, and the

@@ -331,6 +331,8 @@ _VARIANTS = [
     ("source_tables_in_two_launches", {"PDR_FUSED_OPTS": "SPLIT_SOURCE_TABLES=1"}, False),
     ("query_features_gathered_into_sorted_order", {"PDR_FUSED_OPTS": "QUERIES_IN_PLACE=0"}, False),
     ("query_conv_in_its_place", {"PDR_FUSED_OPTS": "QUERY_CONV_AHEAD=0"}, True),
+    # every launch walking its tiles against its producer's direction (pdr_layer_in_t.walk_reverse): order in time only
+    ("tiles_walked_against_the_producer", {"PDR_FUSED_OPTS": "ZIGZAG_WALK=1"}, True),
 ]
 
 
@@ -1922,6 +1924,68 @@ def test_adaptive_sampler_is_reproducible_from_a_seed(cuda):
         forms.append(dict(s.mode_counts))
     assert forms[0] == forms[1], forms
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- round 6: row tiles walked from the last to the first ---------------------------------------------------------------
+@pytest.mark.parametrize("B,rpb,Cin,Cout,form", [(16, 2048, 128, 128, "plain"), (8, 1024, 171, 128, "plain"),
+                                                 (16, 4096, 32, 32, "plain"), (3, 1000, 64, 64, "plain"),
+                                                 (16, 2048, 128, 128, "residual"), (8, 2048, 41, 32, "ball"),
+                                                 (8, 2048, 105, 128, "knn")])
+def test_layer_walked_backwards_writes_the_same_bytes(cuda, B, rpb, Cin, Cout, form):
+    """pdr_layer_in_t.walk_reverse changes the ORDER IN TIME of a launch's row tiles, nothing else: outputs and per-tile
+    statistics of the forward and the reversed walk are the same bytes -- whole groups of 8 clouds (the XCD-local tile
+    order) and not, a ragged last tile, plain / residual / ball- and kNN-gathered sources."""
+    lib, dev = _lib.load(), cuda
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(B + rpb + Cin)
+    P, ldx, ldw = B * rpb, (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    X = torch.randn(P, ldx, device=dev, generator=g)
+    R = torch.randn(P, ldx, device=dev, generator=g)
+    Wt = torch.randn(Cin, ldw, device=dev, generator=g) * 0.1
+    bias = torch.randn(Cout, device=dev, generator=g)
+    scale = torch.rand(B, Cin, device=dev, generator=g) + 0.5
+    shift = torch.randn(B, Cin, device=dev, generator=g)
+    K, n_src = 8, 512
+    U = torch.randn(B * n_src + 1, ldx, device=dev, generator=g)
+    V2 = torch.randn(P // K, 2 * ldx, device=dev, generator=g)
+    idx = torch.randint(0, n_src, (P,), device=dev, dtype=torch.int32, generator=g)
+    cnt = torch.randint(1, K + 1, (P // K,), device=dev, dtype=torch.int32, generator=g)
+    s1, s2 = torch.rand(P, device=dev, generator=g), torch.rand(P, device=dev, generator=g)
+    r1, r2 = torch.randn(ldx + 4, device=dev, generator=g), torch.randn(ldx + 4, device=dev, generator=g)
+
+    def run(reverse):
+        li = _lib.LayerIn()
+        li.n_seg = 1
+        li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = X.data_ptr(), Cin, ldx, 1
+        li.scale, li.shift, li.post_relu, li.rows_per_batch = scale.data_ptr(), shift.data_ptr(), 1, rpb
+        if form == "residual":
+            li.rseg.ptr, li.rseg.C, li.rseg.ld, li.rseg.row_div = R.data_ptr(), Cin, ldx, 1
+        if form in ("ball", "knn"):
+            li.seg[0].ptr = U.data_ptr()
+            li.seg[0].gV, li.seg[0].gV0 = V2.data_ptr(), V2.data_ptr() + 4 * ldx
+            li.seg[0].g_ldv, li.seg[0].g_nsrc, li.seg[0].g_zrow = 2 * ldx, n_src, B * n_src
+            li.gidx, li.gcnt, li.gK = idx.data_ptr(), cnt.data_ptr(), K
+            if form == "knn":
+                li.gcnt, li.seg[0].gV0 = None, None
+                li.gs1, li.gs2 = s1.data_ptr(), s2.data_ptr()
+                li.seg[0].g_r1, li.seg[0].g_r2 = r1.data_ptr(), r2.data_ptr()
+        li.walk_reverse = int(reverse)
+        tm = lib.pdr_fused_layer_tile_rows(rpb, Cout)
+        tpb = (rpb + tm - 1) // tm
+        Y = torch.full((P, ldw), float("nan"), device=dev)
+        part = torch.full((B * tpb, Cout, 2), float("nan"), device=dev)
+        _lib.check(lib.pdr_fused_layer(ctypes.byref(li), P, Cin, Wt.data_ptr(), ldw, bias.data_ptr(), Cout, Y.data_ptr(),
+                                       ldw, part.data_ptr(), Cout, st), "layer")
+        torch.cuda.synchronize()
+        return Y[:, :Cout].clone(), part.clone()
+    y0, p0 = run(False)
+    y1, p1 = run(True)
+    assert bool(torch.isfinite(y0).all()) and bool(torch.isfinite(p0).all())
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    if form == "plain":
+        x = torch.relu(X[:, :Cin].double().view(B, rpb, Cin) * scale.double()[:, None] + shift.double()[:, None])
+        want = x.view(P, Cin) @ Wt[:, :Cout].double() + bias.double()
+        assert _rel(y1.double(), want) < 2e-5
 
 
 # ---- round 6: row map of the per-query term, paired launches ---------------------------------------------------------

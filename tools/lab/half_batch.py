@@ -29,8 +29,8 @@ def build(lib, B, rpb, C, layers, dev):
     shift = [torch.zeros(B, C, device=dev)] + [torch.empty(B, C, device=dev) for _ in range(layers)]
     keep = (acts, Ws, bias, gamma, beta, partial, scale, shift)
 
-    def run(b0, nb, st):
-        """the chain over clouds b0 .. b0 + nb - 1 on stream st"""
+    def run(b0, nb, st, zigzag=False):
+        """the chain over clouds b0 .. b0 + nb - 1 on stream st (zigzag: every other layer walks its tiles backwards)"""
         for l in range(layers):
             li = _lib.LayerIn()
             li.n_seg = 1
@@ -38,6 +38,7 @@ def build(lib, B, rpb, C, layers, dev):
             li.seg[0].ptr, li.seg[0].C, li.seg[0].ld, li.seg[0].row_div = x.data_ptr(), C, C, 1
             li.scale, li.shift = scale[l][b0:].data_ptr(), shift[l][b0:].data_ptr()
             li.pre_relu, li.post_relu, li.rows_per_batch = 0, 1 if l else 0, rpb
+            li.walk_reverse = (l & 1) if zigzag else 0
             y, p = acts[l + 1][b0 * rpb:], partial[l][b0 * tpb:]
             _lib.check(lib.pdr_fused_layer(ctypes.byref(li), nb * rpb, C, Ws[l].data_ptr(), C, bias[l].data_ptr(), C,
                                            y.data_ptr(), C, p.data_ptr(), C, st), "fused_layer")
@@ -68,6 +69,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--zigzag", action="store_true", help="instead of parts: the whole batch, every other layer walking "
+                    "its row tiles from the last to the first (pdr_layer_in_t.walk_reverse)")
+    ap.add_argument("--serial", action="store_true", help="the parts one after the other on ONE stream (each part's "
+                    "activations may then stay in the 256-MB memory-side cache from one layer to the next)")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -82,6 +87,13 @@ def main():
     def parts():
         main_s = torch.cuda.current_stream()
         nb = B // args.parts
+        if args.zigzag:
+            run(0, B, main_s.cuda_stream, zigzag=True)
+            return
+        if args.serial:
+            for i in range(args.parts):
+                run(i * nb, nb, main_s.cuda_stream)
+            return
         for i, s in enumerate(side):
             s.wait_stream(main_s)
             with torch.cuda.stream(s):
@@ -106,7 +118,7 @@ def main():
         else:
             print("same bits:", bool(torch.equal(ref, y)))
     print("rpb=%d C=%d layers=%d B=%d: whole %.1f us, %d parts on %d streams %.1f us (%.3f x)" %
-          (args.rpb, args.c, args.layers, B, out["whole"], args.parts, args.parts, out["parts"],
+          (args.rpb, args.c, args.layers, B, out["whole"], args.parts, 1 if args.serial else args.parts, out["parts"],
            out["whole"] / out["parts"]))
 
 
