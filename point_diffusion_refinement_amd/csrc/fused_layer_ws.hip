@@ -348,7 +348,11 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
       const int lt = row_tile(c.tile);
       const int bl = lt / tpb, tb = lt - bl * tpb;
       const int b = bl * cloud_mul + cloud_add;
+#ifdef PDR_LAB_SAME_ROWS
+      const long row0 = static_cast<long>(tb & 1) * TM;     // lab: every tile reads the first rows (cache hits)
+#else
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
+#endif
       const int nvalid = min(TM, rpb - tb * TM);
       const pdr_seg_t seg = in.seg[c.sg];
       const int shift = __builtin_ctz(seg.row_div);
@@ -740,7 +744,11 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
       const int bl = lt / tpb, tb = lt - bl * tpb;
       const int b = bl * cloud_mul + cloud_add;
       const int tile = b * ptpb + tb;          // index of the tile's partial row
+#ifdef PDR_LAB_SAME_OUT
+      const long row0 = static_cast<long>(blockIdx.x & 511) * TM;   // lab: a workgroup rewrites one tile's rows
+#else
       const long row0 = static_cast<long>(b) * rpb + static_cast<long>(tb) * TM;
+#endif
       const int nvalid = min(TM, rpb - tb * TM);
       // (weighted statistics -- in.wrow0, the per-query launches of a deduplicated block -- take the per-row path below:
       // a few small launches per step; the full-tile path of every other launch stays as it is)
@@ -920,8 +928,13 @@ __global__ __launch_bounds__(512, (ws_waves_per_simd<RT, CT, RADD, SPLIT>())) vo
                   const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Tt[wave][rr + 8][c4]);
                   if (col4ok) {
                     char* qh = q + (16 * h) * row_bytes;
+#if defined(PDR_LAB_NT_STORE)
+                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(qh + toff));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(qh + 8 * row_bytes + toff));
+#elif !defined(PDR_LAB_NO_STORE)
                     *reinterpret_cast<f32x4*>(qh + toff) = v0;
                     *reinterpret_cast<f32x4*>(qh + 8 * row_bytes + toff) = v1;
+#endif
                   }
                 }
               }
