@@ -1,9 +1,10 @@
-# end-of-round validation on the GPU box: full GPU suite, smoke, the driver's bench line, every profile artefact
-TAG=${1:-r4}
-python -m pytest tests -m gpu -q --maxfail=10 2>&1 | tail -12 > gpurun_out/${TAG}_pytest_gpu.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/${TAG}_smoke.txt
-python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
-bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
-bash tools/lab/split_stats.sh > /dev/null 2>&1 && cp gpurun_out/split_kernel_stats.csv gpurun_out/${TAG}_split_kernel_stats.csv
-python -m tools.lab.split_half > gpurun_out/${TAG}_split_accuracy.json 2>/dev/null
-cat gpurun_out/${TAG}_pytest_gpu.txt gpurun_out/${TAG}_smoke.txt; cut -c1-400 gpurun_out/${TAG}_bench.json
+set -x
+cd $GRAFT_REPO_ROOT
+( time python -m pytest tests -m gpu -x -q ) > gpurun_out/r6_final_tests.log 2>&1
+tail -3 gpurun_out/r6_final_tests.log
+bash tools/profile_round.sh r6 > gpurun_out/r6_profile_round.log 2>&1
+tail -5 gpurun_out/r6_profile_round.log
+( time python bench.py ) > gpurun_out/r6_bench_full.log 2> gpurun_out/r6_bench_full.err
+tail -c 600 gpurun_out/r6_bench_full.log
+MARK_BACK_TO_BACK=6 python -m tools.lab.step_markers gpurun_out/r6_timeline_markers_loop.json > gpurun_out/r6_timeline_markers_loop.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
