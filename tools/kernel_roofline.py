@@ -43,7 +43,8 @@ def _layer_symbol(plan, pool=False):
     ws, vid, radd, gath, vec, split = plan
     t = ", ".join(str(v) for v in _VARIANT[vid])
     if ws:
-        return "fused_layer_ws_kernel<%s, %s, %d, %s, %s>" % (t, _b(radd), int(gath), _b(split), _b(pool))
+        # (the last argument: PAIR, round 6 -- pdr_fused_layer / _pool launches are never the paired form)
+        return "fused_layer_ws_kernel<%s, %s, %d, %s, %s, false>" % (t, _b(radd), int(gath), _b(split), _b(pool))
     return "fused_layer_kernel<%s, %s, %s, %s, %s>" % (t, _b(radd), _b(vec), _b(gath), _b(pool))
 
 
@@ -146,9 +147,13 @@ def measured_traffic(symbol):
     if path is None:
         raise LookupError("no profiles/r*_pmc_traffic.json")
     key = symbol.replace(" ", "")
-    for k in json.load(open(path))["kernels"]:
-        if key in k["kernel"].replace(" ", ""):
-            return k["hbm_bytes_per_launch"], os.path.basename(path)
+    stem = key[:-1] if key.endswith(">") else key       # a profile of a build with more (trailing) template arguments
+    kernels = json.load(open(path))["kernels"]
+    for exact in (True, False):
+        for k in kernels:
+            name = k["kernel"].replace(" ", "")
+            if (key in name) if exact else (stem in name and name[name.index(stem) + len(stem)] in ",>"):
+                return k["hbm_bytes_per_launch"], os.path.basename(path)
     raise LookupError("%s has no entry for %s -- re-run tools/profile_round.sh" % (os.path.basename(path), symbol))
 
 
