@@ -1,7 +1,7 @@
 #!/bin/bash
 # final GPU session of the round: the whole GPU suite (parity records), smoke, the default bench line
 export TMPDIR=/tmp
-O=gpurun_out/r5final
+O=gpurun_out/${1:-r6}final
 mkdir -p $O
 rm -f gpurun_out/parity.json
 timeout 2400 python -m pytest tests -m gpu -q > $O/all.txt 2>&1
