@@ -24,6 +24,7 @@ def main():
         wg = np.zeros((2048, 3), dtype=np.uint64)
         assert raw.pdr_lab_wg_read(wg.ctypes.data_as(ctypes.c_void_p)) == 0
         wg = wg[wg[:, 1] > 0].astype(np.int64)
+    if hasattr(raw, "pdr_lab_wg_read") and len(wg):
         t00 = wg[:, 0].min()
         st, en, dur = (wg[:, 0] - t00) / 100.0, (wg[:, 1] - t00) / 100.0, (wg[:, 1] - wg[:, 0]) / 100.0
         xcc, tiles = wg[:, 2] & 15, wg[:, 2] >> 8
