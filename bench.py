@@ -278,6 +278,7 @@ def config5_fastdpm_refine(device, B):
     S = 50
     sampler = GraphedFastSampler(coarse_net, dh, DIFFUSION_CONFIG, length=S, sampling_method='var',
                                  schedule='quadratic', kappa=0.5, noise='device', use_graph=True)
+    refiner = G.GraphedRefiner(refine_net, 0.001, 8)      # the refinement forward + x8 upsampling as one graph replay
     _, cond, label = synthetic_batch(B, seed=0, device=device)
     gt = torch.rand(B, 16384, 3, device=device) - 0.5
     out, reps = {}, 2
@@ -288,7 +289,7 @@ def config5_fastdpm_refine(device, B):
             coarse = sampler.sample((B, N_POINTS, 3), cond, label)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
-            fine = G.refine_completion(refine_net, coarse, cond, label, 0.001, 8)
+            fine = refiner(coarse, cond, label)
             torch.cuda.synchronize(device)
             t2 = time.perf_counter()
             cd_p, cd_t = calc_cd(fine / 2, gt)

@@ -34,6 +34,12 @@ moments (1e-6 per step; over many steps a near-tie of an FPS pick can resolve di
 """
 import torch
 
+# The first, uncached step of a batch (condition branch + the step itself: ~600 launches, 16-19 ms when the host submits
+# them one by one) as a hipGraph too: captured at the first batch of a shape, BEFORE the cached step's graphs, so that
+# the retained condition features the cached steps read ARE the tensors this graph writes (no copy between batches).
+# Fused network + native update only; False: the eager first step of rounds 1-5 (a variant of the tests).
+FIRST_STEP_GRAPH = True
+
 
 class GraphedReverseSampler:
     # neighbourhoods='adaptive': walked share (tiles walked / tiles of the deduplicable blocks) above which the step
@@ -67,6 +73,7 @@ class GraphedReverseSampler:
         self._sigma_raw = S.to(self.device)            # Sigma[step] of the restart option (sigma_0 not zeroed)
         self._key = None
         self._step_table = None                        # built on first use (needs the subclass's time table)
+        self._first = None                             # (mode, graph, retained tensors) of the captured first step
 
     @property
     def _graph(self):
@@ -180,6 +187,7 @@ class GraphedReverseSampler:
         key = (tuple(size), tuple(condition.shape), None if label is None else tuple(label.shape))
         if self._key != key:
             self._graphs = {}
+            self._first = None
             self._key = key
             self._x = torch.empty(size, device=self.device)
             self._z = torch.empty(size, device=self.device)
@@ -283,17 +291,67 @@ class GraphedReverseSampler:
             torch.cuda.current_stream(self.device).synchronize()   # (nothing of the previous batch still publishes)
         self._probe_host.zero_()                       # no slot of the previous batch can be mistaken for this one's
         self._events = []
-        self._advance_eager(keep_slice)                # first step: condition branch runs and is retained
+        first_graph = self.use_graph and FIRST_STEP_GRAPH and keep_slice is None and self._native() and \
+            hasattr(self.net, "sync_condition") and self.device.type == "cuda"
+        replayed = False
+        if first_graph and self._first is not None and self._first[0] == self._mode:
+            self._replay_first()                       # first step: condition branch + step, one graph replay
+            replayed = True
+        else:
+            state = (self._x, self._t, self._ts, self._rng, self._probe)
+            saved = [v.clone() for v in state] if first_graph and not self._graphs and self._first is None else None
+            self._advance_eager(keep_slice)            # first step: condition branch runs and is retained
+            if saved is not None:
+                self._capture_first(state, saved)      # (once per shape: ahead of the cached step's graphs)
         if self.neighbourhoods == 'adaptive' and self.device.type == "cuda":
             # once per batch: the first step's probe decides the form of the second (a restart from a stored x^step
             # begins on a surface); later steps read the probe of the step two before them, by its step counter (a
             # first step that ran in PyTorch ops -- keep_slice -- published nothing: the default form stays)
             torch.cuda.current_stream(self.device).synchronize()
             self._pick_mode(t0)
-        if self._graphs:
+        if self._graphs and self._first is None:
             self._adopt_cache()
-        if hasattr(self.net, "sync_condition"):
+        if hasattr(self.net, "sync_condition") and not replayed:
             self.net.sync_condition()                  # fused network: refresh its channel-last copies in place
+
+    def _capture_first(self, state, saved):
+        """The first step of a batch as a graph.  Called right after the eager first step of the FIRST batch of a shape
+        (the warm-up) with the state that step started from: capture (fresh condition features are allocated from the
+        graph's pool -- they stay where they are from now on), restore the state, replay once so that the retained
+        tensors hold this batch's values."""
+        def restore():
+            for v, w in zip(state, saved):
+                v.copy_(w)
+        restore()
+        self.net.reset_cond_features()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step()
+        restore()
+        g.replay()
+        net = getattr(self.net, "net", self.net)
+        self._first_lens = {name: (None if getattr(net, name) is None else len(getattr(net, name)))
+                            for name in self._CACHE_ATTRS}
+        self._first = (self._mode, g, self._cache_tensors())
+
+    def _replay_first(self):
+        mode, g, tensors = self._first
+        self._draw_cpu_noise()
+        self.net.reset_cond_features()
+        g.replay()
+        # the Python side of an eager first step: the network points at its retained features, the fused wrapper knows
+        # its channel-last copies and class-embedding rows are those of this batch
+        net = getattr(self.net, "net", self.net)
+        it = iter(tensors)
+        net.global_feature = next(it)
+        lens = self._first_lens
+        for name in self._CACHE_ATTRS:
+            n = lens[name]
+            setattr(net, name, None if n is None else [next(it) for _ in range(n)])
+        self.net._synced = True
+        if self._label is not None:
+            self.net._label_key = (self._label, self._label._version)
+        self.remaining -= 1
 
     def _draw_cpu_noise(self):
         # reference order: one draw per step with t > 0, none at t = 0 (FastDPM: every step)

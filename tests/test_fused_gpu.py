@@ -1926,6 +1926,57 @@ def test_adaptive_sampler_is_reproducible_from_a_seed(cuda):
     assert torch.equal(outs[0], outs[1])
 
 
+# ---- round 6: the first step of a batch and the refinement forward as graphs ---------------------------------------------
+@pytest.mark.parametrize("mode,noise", [("once", "cpu"), ("adaptive", "device"), ("whole", "cpu")])
+def test_first_step_as_a_graph_equals_the_eager_first_step(cuda, monkeypatch, mode, noise):
+    """reverse_sampler.FIRST_STEP_GRAPH: from the second batch of a shape on, the uncached first step (condition branch +
+    step) is a graph replay writing the retained features where the cached step's graphs read them.  Three batches with
+    different conditions / labels / x_T, a few steps each: the same bytes as the sampler with the eager first step."""
+    from point_diffusion_refinement_amd.pointnet2 import reverse_sampler as RS
+    net, fused = _pair(small_fused_config(), 31, cuda)
+    dh = util.calc_diffusion_hyperparams(12, 1e-4, 0.02)
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(3):
+        cond = torch.cat([torch.rand(2, 256, 3, generator=g) * 2 - 1, torch.ones(2, 256, 1)], 2).to(cuda)
+        batches.append((cond, torch.randint(0, 16, (2,), generator=g).to(cuda), torch.randn(2, 128, 3, generator=g).to(cuda)))
+    outs = {}
+    for first_graph in (True, False):
+        monkeypatch.setattr(RS, "FIRST_STEP_GRAPH", first_graph)
+        s = GraphedReverseSampler(fused, dh, noise=noise, use_graph=True, neighbourhoods=mode)
+        res = []
+        for i, (cond, label, xT) in enumerate(batches):
+            torch.manual_seed(100 + i)
+            s.begin((2, 128, 3), cond, label, x_T=xT)
+            res.append(s._x.clone())                       # after the first step
+            s.advance(4)
+            res.append(s._x.clone())
+        assert (s._first is not None) == first_graph
+        outs[first_graph] = res
+    for a, b in zip(outs[True], outs[False]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_graphed_refiner_equals_refine_completion(cuda):
+    """generation.GraphedRefiner: the refinement forward + upsampling as one graph replay per batch == the eager
+    refine_completion on every batch (the first is the eager warm-up itself)."""
+    from point_diffusion_refinement_amd.pointnet2 import generation as G
+    cfg = small_fused_config(include_t=False)
+    cfg["point_upsample_factor"] = 4
+    net, fused = _pair(cfg, 43, cuda)
+    refiner = G.GraphedRefiner(fused, 0.001, 4)
+    g = torch.Generator().manual_seed(9)
+    for i in range(3):
+        cond = torch.cat([torch.rand(2, 256, 3, generator=g) * 2 - 1, torch.ones(2, 256, 1)], 2).to(cuda)
+        label = torch.randint(0, 16, (2,), generator=g).to(cuda)
+        coarse = (torch.rand(2, 128, 3, generator=g) * 2 - 1).to(cuda)
+        with torch.no_grad():
+            got = refiner(coarse, cond, label)
+            want = G.refine_completion(fused, coarse, cond, label, 0.001, 4)
+        assert got.shape == (2, 4 * 128, 3) and bool(torch.isfinite(got).all())
+        assert torch.equal(got, want), (i, float((got - want).abs().max()))
+
+
 # ---- round 6: row tiles walked from the last to the first ---------------------------------------------------------------
 @pytest.mark.parametrize("B,rpb,Cin,Cout,form", [(16, 2048, 128, 128, "plain"), (8, 1024, 171, 128, "plain"),
                                                  (16, 4096, 32, 32, "plain"), (3, 1000, 64, 64, "plain"),
